@@ -1,0 +1,229 @@
+/*
+ * raymond_hip.h — C-ABI of the MI355X-native radiance integrator.
+ *
+ * This library replaces ONE seam of Nyrox/raymond: the per-tile body of the
+ * worker loop in `render_tiled`
+ *
+ *     reference  src/trace.rs:197-205   for y in tile rows { for x in tile cols {
+ *                                           primary = generate_primary_ray(x, y, cam)   (:322-333 / :335-360)
+ *                                           sample  = trace(primary, &context, 1)       (:232-320)
+ *                                           tile.data[..] += sample } }
+ *
+ * Everything below that loop (Scene::intersect core/src/scene.rs:54-74, the
+ * primitives core/src/geometry/primitives/{sphere,plane,triangle,aabb}.rs, the DDA grid walk
+ * core/src/geometry/acc_grid.rs:89-185, the BRDF and samplers
+ * src/trace.rs:362-416) runs inside one HIP kernel for gfx950.  Everything
+ * above it (tile queue, progressive passes, TaskHandle, tone-map, file IO)
+ * stays with the host.  There is no reference FFI for this path (the reference
+ * has no `extern "C"` anywhere); the entry points below are what a cgo-style
+ * Rust `extern "C"` block for that seam would bind — INTEGRATION.md shows the
+ * Rust side.
+ *
+ * Conventions: plain C, POD structs, caller owns every buffer it passes, the
+ * library owns the opaque handles.  Every function returns rmd_status
+ * (0 = OK); nothing throws or aborts across the boundary (the reference's
+ * failure mode is a Rust panic; here it is a status + rmd_last_error()).
+ * A context is thread-compatible (one calling thread at a time per handle).
+ * All arithmetic is IEEE binary64, as in the reference (core/src/math.rs:10).
+ */
+#ifndef RAYMOND_HIP_H
+#define RAYMOND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMD_ABI_VERSION 1u
+
+typedef int32_t rmd_status;
+enum {
+	RMD_OK = 0,
+	RMD_ERR_INVALID_ARGUMENT = 1, /* null pointer, zero size, out-of-range index            */
+	RMD_ERR_NO_DEVICE = 2,        /* HIP runtime present but no usable gfx950 device         */
+	RMD_ERR_HIP = 3,              /* a HIP call failed; text in rmd_last_error               */
+	RMD_ERR_OUT_OF_MEMORY = 4,
+	RMD_ERR_GRID_INDEX = 5,       /* grid build hit the reference's out-of-bounds panic (Q5) */
+	RMD_ERR_UNSUPPORTED = 6,      /* e.g. bounce_limit above RMD_MAX_BOUNCE_LIMIT            */
+	RMD_ERR_RCCL = 7
+};
+
+/* ---- scene description (mirrors core/src/scene.rs:8-45, core/src/lib.rs:21-26) ---- */
+
+/* enum Geometry { Plane, Sphere, Grid }  — core/src/scene.rs:9-13 (same order) */
+enum { RMD_GEOM_PLANE = 0, RMD_GEOM_SPHERE = 1, RMD_GEOM_GRID = 2 };
+/* enum Material { Diffuse, Metal, Emission } — core/src/lib.rs:21-26 (same order) */
+enum { RMD_MAT_DIFFUSE = 0, RMD_MAT_METAL = 1, RMD_MAT_EMISSION = 2 };
+
+/* Material::Diffuse(color, roughness) | Metal(color, roughness) | Emission(e, v2, f1, f2).
+ * For Emission `color` carries the first vector (the only field trace() reads,
+ * src/trace.rs:250-252); v2/f1/f2 ride along untouched in `emission_aux`. */
+typedef struct rmd_material {
+	uint32_t kind;
+	uint32_t _pad;
+	double color[3];
+	double roughness;
+	double emission_aux[5];
+} rmd_material;
+
+/* One scene::Object (core/src/scene.rs:33-37).  Object order is significant:
+ * Scene::intersect keeps the FIRST object on distance ties (strict '<', :61). */
+typedef struct rmd_object {
+	uint32_t geometry_kind;
+	uint32_t grid_index; /* RMD_GEOM_GRID: index into the grids array           */
+	double origin[3];    /* Plane.origin (plane.rs:6) / Sphere.origin (sphere.rs:6) */
+	double normal[3];    /* Plane.normal (plane.rs:7)                            */
+	double radius;       /* Sphere.radius (sphere.rs:7)                          */
+	rmd_material material;
+} rmd_object;
+
+/* One AccGrid (core/src/geometry/acc_grid.rs:27-33) in the compact layout:
+ * `cells[c]` = offset into `mapping_table`; `mapping_table[off]` = count,
+ * followed by `count` triangle indices (acc_grid.rs:67-74), both as u32
+ * instead of usize.  Triangles are split SoA-by-role: positions (read by every
+ * Möller-Trumbore test, triangle.rs:11-44) and vertex normals (read only on a
+ * shaded hit, triangle.rs:47-68) instead of the 264-byte AoS Triangle.
+ * All pointers are HOST pointers; rmd_scene_create copies them to HBM. */
+typedef struct rmd_grid_desc {
+	double bbox_min[3]; /* mesh.bounding_box.min (mesh.rs:123-140)      */
+	double bbox_max[3];
+	uint32_t resolution[3]; /* acc_grid.rs:6-17                          */
+	uint32_t _pad;
+	double cell_size[3]; /* acc_grid.rs:38                               */
+	const uint32_t *cells;
+	uint64_t n_cells; /* = res.x*res.y*res.z                            */
+	const uint32_t *mapping_table;
+	uint64_t n_mapping;
+	const double *tri_pos; /* n_tris * 9: v0.xyz v1.xyz v2.xyz          */
+	const double *tri_nrm; /* n_tris * 9: n0.xyz n1.xyz n2.xyz          */
+	uint64_t n_tris;
+} rmd_grid_desc;
+
+/* CameraSettings (src/trace.rs:32-40) + Transform (src/transform.rs:4-7, position only). */
+typedef struct rmd_camera {
+	uint32_t backbuffer_width;
+	uint32_t backbuffer_height;
+	double fov_vert; /* degrees */
+	double position[3];
+	double focal_length;
+	double aperture_radius; /* > 0 selects generate_primary_ray_with_dof (trace.rs:335-360);
+	                           0 selects generate_primary_ray (:322-333), which is what the
+	                           reference's worker calls (:199).  Gated because with radius 0
+	                           the reference's rejection loop never terminates. */
+} rmd_camera;
+
+#define RMD_MAX_BOUNCE_LIMIT 16u
+
+/* The part of Settings (src/trace.rs:42-55) the per-tile body reads, plus the
+ * RNG definition the reference lacks (it uses the unseedable thread_rng). */
+typedef struct rmd_settings {
+	uint32_t bounce_limit; /* Settings.bounce_limit; trace() starts at depth 1 (:200,:235) */
+	uint32_t sample_begin; /* first sample index s of this pass                             */
+	uint32_t sample_count; /* number of consecutive samples to add per pixel               */
+	uint32_t _pad;
+	uint64_t seed; /* Philox key; see "RNG" below                                   */
+} rmd_settings;
+
+/* core::tile::Tile geometry (core/src/tile.rs:7-14) without the sample buffer. */
+typedef struct rmd_tile_rect {
+	uint32_t left, top, width, height;
+} rmd_tile_rect;
+
+/*
+ * RNG (replaces rand::random::<f64>() at src/trace.rs:260,287,288,326,327,340,341,397,398).
+ * Counter-based Philox4x32-10 (Salmon et al., SC'11), key = (seed lo32, seed hi32),
+ * counter = (pixel = y*W + x, sample index, draw_index >> 1, 0).  The block's
+ * four words w0..w3 give two uniforms:  draw_index even -> (w1:w0), odd -> (w3:w2),
+ * u = (((uint64)hi << 32 | lo) >> 11) * 2^-53  in [0,1).  draw_index counts the
+ * calls the reference makes, in its order, within one sample: 0,1 = pixel jitter
+ * x,y (:326-327); DoF rejection draws follow (:340-341); then per shaded depth
+ * r (:260), r1, r2 (:397-398 or :287-288).
+ */
+
+typedef struct rmd_context rmd_context;
+typedef struct rmd_scene rmd_scene;
+typedef struct rmd_comm rmd_comm;
+
+/* ---- lifetime ---- */
+uint32_t rmd_abi_version(void);
+/* One context per GPU (device_ordinal = HIP device index).  Creates its own stream. */
+rmd_status rmd_context_create(int32_t device_ordinal, rmd_context **out);
+/* Same, but launches on a caller-owned hipStream_t (passed as void*, 0 = null stream). */
+rmd_status rmd_context_create_on_stream(int32_t device_ordinal, void *hip_stream, rmd_context **out);
+void rmd_context_destroy(rmd_context *ctx);
+/* Text of the last failure on this context (or of the last failed context-less call when ctx = NULL). */
+const char *rmd_last_error(const rmd_context *ctx);
+
+/* Uploads the object table and the grids to HBM.  Replaces the per-worker
+ * `scene.clone()` (src/trace.rs:182-185): one resident copy per GPU. */
+rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_t n_objects,
+                            const rmd_grid_desc *grids, uint32_t n_grids, rmd_scene **out);
+void rmd_scene_destroy(rmd_scene *scene);
+
+/* ---- device buffers for hosts without their own HIP binding ---- */
+rmd_status rmd_framebuffer_alloc(rmd_context *ctx, uint32_t width, uint32_t height, double **out_dev); /* zeroed W*H*3 */
+rmd_status rmd_framebuffer_free(rmd_context *ctx, double *dev);
+rmd_status rmd_framebuffer_zero(rmd_context *ctx, double *dev, size_t n_doubles);
+rmd_status rmd_framebuffer_download(rmd_context *ctx, const double *dev, double *host, size_t n_doubles);
+rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *dev, size_t n_doubles);
+
+/*
+ * The hot path.  For every pixel (x,y) of every rect in `tiles`:
+ *     accum[(x + y*W)*3 + c] += sample(x,y,s).c   for s = sample_begin .. sample_begin+sample_count-1, in that order
+ * i.e. `sample_count` consecutive executions of src/trace.rs:197-205 over those
+ * tiles.  Dividing by the sample count stays with the caller (TaskHandle::await,
+ * src/trace.rs:95).  `accum_dev` is a DEVICE pointer to W*H*3 doubles, row-major
+ * RGB (x + y*W, the layout await() assembles, :97).  Rects must lie inside the
+ * backbuffer and must not overlap each other within one call.
+ * Synchronous: returns after the kernel has completed.
+ */
+rmd_status rmd_render_tiles(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera,
+                            const rmd_settings *settings, const rmd_tile_rect *tiles, uint32_t n_tiles,
+                            double *accum_dev);
+/* Same, enqueue only; pair with rmd_context_synchronize (lets one host thread drive several GPUs). */
+rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera,
+                                  const rmd_settings *settings, const rmd_tile_rect *tiles, uint32_t n_tiles,
+                                  double *accum_dev);
+rmd_status rmd_context_synchronize(rmd_context *ctx);
+/* Host-buffer convenience for a caller that keeps Tile.data in RAM, as the
+ * reference does: upload accum, render, download (PCIe-inclusive). */
+rmd_status rmd_render_tiles_host(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera,
+                                 const rmd_settings *settings, const rmd_tile_rect *tiles, uint32_t n_tiles,
+                                 double *accum_host);
+/* Duration of the most recent render kernel on this context, from HIP events
+ * recorded on the context's stream around the launch (valid after a sync). */
+rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms);
+
+/* ---- output stage (TaskHandle::await src/trace.rs:93-99, cli_old/src/main.rs:155-181) ---- */
+/* out_rgb8[i] = trunc(255 * (1 - exp(-(accum[i]/sample_count) * exposure))^(1/gamma)); device in, host out. */
+rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32_t width, uint32_t height,
+                               uint32_t sample_count, double exposure, double gamma, uint8_t *out_rgb8_host);
+
+/* ---- multi-GPU (no reference counterpart; the reference has no collectives) ---- */
+#define RMD_COMM_ID_BYTES 128
+/* rank 0 calls rmd_comm_unique_id and ships the 128 bytes to the other ranks by any means. */
+rmd_status rmd_comm_unique_id(uint8_t id_out[RMD_COMM_ID_BYTES]);
+rmd_status rmd_comm_create(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES], int32_t rank, int32_t world_size,
+                           rmd_comm **out);
+void rmd_comm_destroy(rmd_comm *comm);
+/* In-place ncclReduce(sum, f64) of the accumulated framebuffer to `root` over xGMI.
+ * Every pixel is non-zero on exactly one rank, so the sum is bit-identical to a 1-GPU render. */
+rmd_status rmd_reduce_framebuffer(rmd_comm *comm, double *accum_dev, size_t n_doubles, int32_t root);
+
+/* ---- host-side grid build (AccGrid::build_from_mesh, core/src/geometry/acc_grid.rs:6-83) ---- */
+typedef struct rmd_grid_build rmd_grid_build; /* owns the arrays a rmd_grid_desc points at */
+/* tri_pos/tri_nrm: n_tris*9 doubles each (host).  Computes mesh bounds (mesh.rs:123-140), resolution,
+ * cell_size, cells, mapping_table.  RMD_ERR_GRID_INDEX where the reference would panic on the
+ * `x + res.x*(y + z*res.z)` index (acc_grid.rs:61) running past the cell array. */
+rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const double *tri_nrm, uint64_t n_tris,
+                                    rmd_grid_build **out);
+/* Fills `desc` with pointers into `build` (valid until rmd_grid_build_destroy). */
+rmd_status rmd_grid_build_describe(const rmd_grid_build *build, rmd_grid_desc *desc);
+void rmd_grid_build_destroy(rmd_grid_build *build);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYMOND_HIP_H */

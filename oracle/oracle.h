@@ -1,0 +1,92 @@
+/*
+ * oracle.h — C entry points of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a CPU restatement of the reference's
+ * per-pixel radiance loop (Nyrox/raymond, src/trace.rs + core/src/{scene,geometry}),
+ * used as the parity checker and as the timed "port" CPU baseline.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * Nothing under raymond_amd/ links, imports or calls it.
+ *
+ * PARITY UNPINNED by reference tests: the reference has no tests, fixtures or
+ * golden vectors for this path and cannot be compiled here (no Rust toolchain),
+ * so the restatement is pinned only by (a) the Random123 known-answer vectors
+ * for the RNG, (b) hand-derived known answers per primitive, and (c) a
+ * statistical comparison with examples/ReflectiveSpheres.png (block means
+ * committed under tests/golden/).
+ *
+ * The scene POD types are shared with the product header (inputs only).
+ */
+#ifndef RMD_ORACLE_H
+#define RMD_ORACLE_H
+
+#include "../include/raymond_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+/* RNG */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double orc_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw_index);
+
+/* Batched device-function KATs.  Rays are 6 doubles (origin xyz, direction xyz).
+ * hit[i] = 1/0; t[i] valid when hit. */
+void orc_sphere_intersect(size_t n, const double *sphere4, const double *ray6, int32_t *hit, double *t);
+void orc_sphere_normal(size_t n, const double *sphere4, const double *ray6, const double *t, double *n3);
+void orc_plane_intersect(size_t n, const double *plane6, const double *ray6, int32_t *hit, double *t);
+void orc_aabb_intersect(size_t n, const double *aabb6, const double *ray6, int32_t *hit, double *t);
+void orc_triangle_intersect(size_t n, const double *pos9, const double *ray6, int32_t *hit, double *t);
+void orc_triangle_normal(size_t n, const double *pos9, const double *nrm9, const double *ray6, const double *t,
+                         double *n3);
+void orc_onb(size_t n, const double *n3, double *t3, double *b3);
+void orc_cosine_hemisphere(size_t n, const double *r1, const double *r2, double *dir3, double *pdf);
+void orc_importance_sample_ggx(size_t n, const double *reflect3, const double *rough, const double *r1,
+                               const double *r2, double *dir3);
+void orc_ggx_distribution(size_t n, const double *n3, const double *h3, const double *rough, double *out);
+void orc_geometry_smith(size_t n, const double *n3, const double *v3, const double *l3, const double *rough,
+                        double *out);
+void orc_fresnel_schlick(size_t n, const double *cos_theta, const double *f0_3, double *out3);
+/* jitter uniforms given explicitly: u2[2*i], u2[2*i+1] */
+void orc_primary_ray(size_t n, const rmd_camera *cam, const uint32_t *xy2, const double *u2, double *ray6);
+
+/* grid build (acc_grid.rs:6-83).  Two-call protocol: sizes first, then fill. */
+typedef struct orc_grid orc_grid;
+int32_t orc_grid_build(const double *tri_pos, const double *tri_nrm, uint64_t n_tris, orc_grid **out); /* 0 ok, 5 = index panic */
+void orc_grid_describe(const orc_grid *g, rmd_grid_desc *desc);
+void orc_grid_destroy(orc_grid *g);
+
+/* scene */
+orc_scene *orc_scene_create(const rmd_object *objects, uint32_t n_objects, const rmd_grid_desc *grids,
+                            uint32_t n_grids);
+void orc_scene_destroy(orc_scene *s);
+/* Scene::intersect: obj[i] = object index or -1; sub[i] = triangle index for grids */
+void orc_scene_intersect(const orc_scene *s, size_t n, const double *ray6, int32_t *obj, double *t, uint32_t *sub);
+/* AccGrid::intersects on grid g of the scene */
+void orc_grid_intersect(const orc_scene *s, uint32_t g, size_t n, const double *ray6, int32_t *hit, double *t,
+                        uint32_t *tri);
+
+/* One sample (generate_primary_ray[_with_dof] + trace(…,1)).  path_obj/path_sub: up to
+ * RMD_MAX_BOUNCE_LIMIT+1 entries of (object index or -1, triangle index) per depth reached; returns depth count. */
+int32_t orc_trace_sample(const orc_scene *s, const rmd_camera *cam, const rmd_settings *st, uint32_t x, uint32_t y,
+                         uint32_t sample, double rgb[3], int32_t *path_obj, uint32_t *path_sub);
+/* Batched: rgb_out[3*i] for (xy[2i], xy[2i+1], sample[i]). */
+void orc_trace_samples(const orc_scene *s, const rmd_camera *cam, const rmd_settings *st, size_t n,
+                       const uint32_t *xy2, const uint32_t *sample, double *rgb_out);
+
+/* The tile worker pool (render_tiled, src/trace.rs:137-230): `n_threads` workers, shared FIFO
+ * queue, one sample pass per pop, accum[(x+y*W)*3+c] += sample.  n_threads = 0 -> hardware_concurrency. */
+void orc_render_tiles(const orc_scene *s, const rmd_camera *cam, const rmd_settings *st, const rmd_tile_rect *tiles,
+                      uint32_t n_tiles, double *accum, uint32_t n_threads);
+
+/* Work counters summed over all threads since the last reset (feed the algorithmic-bytes figure):
+ * [0] samples, [1] path segments (Scene::intersect calls), [2] grid cells visited, [3] triangle tests,
+ * [4] mesh hits shaded (Triangle::get_surface_properties calls), [5] shaded bounces, [6] rng draws, [7] grid walks */
+void orc_counters_reset(void);
+void orc_counters_get(uint64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,379 @@
+// C-ABI implementation (include/raymond_hip.h): contexts, scene upload, the render entry points,
+// framebuffer helpers and the resolve/tone-map epilogue.  Host code only; kernels are in kernels.hip.
+#define RMD_WITH_HIP 1
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "internal.hpp"
+#include "launch.hpp"
+
+namespace {
+thread_local std::string tl_last_error;
+
+#define RMD_HIP(ctx, call)                                                                                      \
+	do {                                                                                                        \
+		hipError_t e_ = (call);                                                                                 \
+		if (e_ != hipSuccess) return rmd::fail(ctx, e_ == hipErrorOutOfMemory ? RMD_ERR_OUT_OF_MEMORY : RMD_ERR_HIP, \
+		                                       std::string(#call) + ": " + hipGetErrorString(e_));              \
+	} while (0)
+
+rmd_status bind(rmd_context *ctx) {
+	if (!ctx) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "null context");
+	RMD_HIP(ctx, hipSetDevice(ctx->device));
+	return RMD_OK;
+}
+
+rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, rmd_context **out) {
+	if (!out) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_create: null out pointer");
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0)
+		return rmd::fail(nullptr, RMD_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+	if (device < 0 || device >= count) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_create: device ordinal out of range");
+	RMD_HIP(nullptr, hipSetDevice(device));
+	hipDeviceProp_t prop;
+	RMD_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return rmd::fail(nullptr, RMD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+	rmd_context *ctx = new (std::nothrow) rmd_context();
+	if (!ctx) return rmd::fail(nullptr, RMD_ERR_OUT_OF_MEMORY, "rmd_context_create: allocation failed");
+	ctx->device = device;
+	if (own_stream) {
+		hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+		if (se != hipSuccess) {
+			delete ctx;
+			return rmd::fail(nullptr, RMD_ERR_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(se));
+		}
+		ctx->owns_stream = true;
+	} else {
+		ctx->stream = stream;
+	}
+	if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+		rmd_context_destroy(ctx);
+		return rmd::fail(nullptr, RMD_ERR_HIP, "hipEventCreate failed");
+	}
+	*out = ctx;
+	return RMD_OK;
+}
+
+// Splits host tiles (core::tile::Tile rectangles) into 8x8 wave tiles; cached per context while the
+// rect list stays the same (a progressive render re-submits the same tiles every pass).
+rmd_status prepare_wave_tiles(rmd_context *ctx, const rmd_camera *cam, const rmd_tile_rect *tiles, uint32_t n_tiles) {
+	const uint32_t W = cam->backbuffer_width, H = cam->backbuffer_height;
+	if (ctx->d_wave_tiles && ctx->cached_W == W && ctx->cached_H == H && ctx->cached_rects.size() == n_tiles &&
+	    (n_tiles == 0 || std::memcmp(ctx->cached_rects.data(), tiles, sizeof(rmd_tile_rect) * n_tiles) == 0))
+		return RMD_OK;
+	std::vector<rmd::WaveTile> wt;
+	for (uint32_t i = 0; i < n_tiles; i++) {
+		const rmd_tile_rect &r = tiles[i];
+		if (r.width == 0 || r.height == 0) continue;
+		if ((uint64_t)r.left + r.width > W || (uint64_t)r.top + r.height > H)
+			return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_render_tiles: tile rectangle outside the backbuffer");
+		for (uint32_t y = r.top; y < r.top + r.height; y += 8)
+			for (uint32_t x = r.left; x < r.left + r.width; x += 8) {
+				rmd::WaveTile t;
+				t.x0 = (uint16_t)x, t.y0 = (uint16_t)y;
+				t.w = (uint8_t)((r.left + r.width - x) < 8u ? (r.left + r.width - x) : 8u);
+				t.h = (uint8_t)((r.top + r.height - y) < 8u ? (r.top + r.height - y) : 8u);
+				t._pad = 0;
+				wt.push_back(t);
+			}
+	}
+	if (wt.size() > ctx->wave_tiles_capacity) {
+		if (ctx->d_wave_tiles) RMD_HIP(ctx, hipFree(ctx->d_wave_tiles));
+		ctx->d_wave_tiles = nullptr, ctx->wave_tiles_capacity = 0;
+		RMD_HIP(ctx, hipMalloc((void **)&ctx->d_wave_tiles, wt.size() * sizeof(rmd::WaveTile)));
+		ctx->wave_tiles_capacity = wt.size();
+	}
+	if (!wt.empty()) {
+		RMD_HIP(ctx, hipMemcpyAsync(ctx->d_wave_tiles, wt.data(), wt.size() * sizeof(rmd::WaveTile), hipMemcpyHostToDevice, ctx->stream));
+		RMD_HIP(ctx, hipStreamSynchronize(ctx->stream)); // wt is a stack-owned staging vector
+	}
+	ctx->n_wave_tiles = (uint32_t)wt.size();
+	ctx->cached_rects.assign(tiles, tiles + n_tiles);
+	ctx->cached_W = W, ctx->cached_H = H;
+	return RMD_OK;
+}
+
+rmd_status check_render_args(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *st) {
+	if (!scene || !cam || !st) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: null scene/camera/settings");
+	if (scene->ctx != ctx) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: scene belongs to another context");
+	if (cam->backbuffer_width == 0 || cam->backbuffer_height == 0 || cam->backbuffer_width > 65535u || cam->backbuffer_height > 65535u)
+		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: backbuffer size must be 1..65535 per axis");
+	if (st->bounce_limit > RMD_MAX_BOUNCE_LIMIT) return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: bounce_limit above RMD_MAX_BOUNCE_LIMIT");
+	if ((uint64_t)st->sample_begin + st->sample_count > 0xFFFFFFFFull) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: sample range overflows u32");
+	if (rmd::render_lds_bytes(scene->n_objects, st->bounce_limit) > 160u * 1024u)
+		return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: object table + bounce stack exceed the 160 KiB LDS of a CU");
+	return RMD_OK;
+}
+
+} // namespace
+
+namespace rmd {
+
+rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text) {
+	if (ctx) ctx->last_error = text;
+	tl_last_error = text;
+	return status;
+}
+
+// generate_primary_ray's loop-invariant terms (src/trace.rs:323-330), evaluated with the host libm
+RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *st) {
+	const double PI = 3.14159265358979323846;
+	RenderParams P;
+	std::memset(&P, 0, sizeof(P));
+	for (int a = 0; a < 3; a++) P.cam_pos[a] = cam->position[a];
+	P.width = (double)cam->backbuffer_width;
+	P.height = (double)cam->backbuffer_height;
+	P.aspect = P.width / P.height;
+	P.tan_half_fov = std::tan(cam->fov_vert / 2.0 * PI / 180.0);
+	P.focal_length = cam->focal_length;
+	P.aperture_radius = cam->aperture_radius;
+	P.W = cam->backbuffer_width, P.H = cam->backbuffer_height;
+	P.bounce_limit = st->bounce_limit;
+	P.sample_begin = st->sample_begin, P.sample_count = st->sample_count;
+	P.n_objects = scene ? scene->n_objects : 0;
+	P.key0 = (uint32_t)st->seed, P.key1 = (uint32_t)(st->seed >> 32);
+	P.use_dof = cam->aperture_radius > 0.0 ? 1u : 0u;
+	return P;
+}
+
+} // namespace rmd
+
+extern "C" {
+
+uint32_t rmd_abi_version(void) { return RMD_ABI_VERSION; }
+
+rmd_status rmd_context_create(int32_t device_ordinal, rmd_context **out) { return context_create(device_ordinal, nullptr, true, out); }
+
+rmd_status rmd_context_create_on_stream(int32_t device_ordinal, void *hip_stream, rmd_context **out) {
+	return context_create(device_ordinal, (hipStream_t)hip_stream, false, out);
+}
+
+void rmd_context_destroy(rmd_context *ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream || !ctx->owns_stream) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx->d_wave_tiles) (void)hipFree(ctx->d_wave_tiles);
+	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+const char *rmd_last_error(const rmd_context *ctx) { return ctx ? ctx->last_error.c_str() : tl_last_error.c_str(); }
+
+rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_t n_objects, const rmd_grid_desc *grids, uint32_t n_grids,
+                            rmd_scene **out) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!out || (n_objects && !objects) || (n_grids && !grids)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: null argument");
+	*out = nullptr;
+	std::vector<rmd::DevObject> hobj(n_objects);
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const rmd_object &o = objects[i];
+		rmd::DevObject &d = hobj[i];
+		std::memset(&d, 0, sizeof(d));
+		if (o.geometry_kind > RMD_GEOM_GRID) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: unknown geometry kind");
+		if (o.material.kind > RMD_MAT_EMISSION) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: unknown material kind");
+		if (o.geometry_kind == RMD_GEOM_GRID && o.grid_index >= n_grids) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: grid_index out of range");
+		d.geometry_kind = o.geometry_kind, d.grid_index = o.grid_index, d.material_kind = o.material.kind;
+		for (int a = 0; a < 3; a++) d.origin[a] = o.origin[a], d.normal[a] = o.normal[a], d.color[a] = o.material.color[a];
+		d.radius = o.radius;
+		d.roughness = o.material.roughness;
+		d.metalness = o.material.kind == RMD_MAT_METAL ? 1.0 : 0.0; // src/trace.rs:248-249
+	}
+	rmd_scene *sc = new (std::nothrow) rmd_scene();
+	if (!sc) return rmd::fail(ctx, RMD_ERR_OUT_OF_MEMORY, "rmd_scene_create: allocation failed");
+	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids;
+	auto upload = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
+		*dst = nullptr;
+		hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+		if (e != hipSuccess) return e;
+		sc->owned.push_back(*dst);
+		if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+		return e;
+	};
+#define RMD_SCENE_HIP(call)                                                                     \
+	do {                                                                                        \
+		hipError_t e_ = (call);                                                                 \
+		if (e_ != hipSuccess) {                                                                 \
+			rmd_scene_destroy(sc);                                                              \
+			return rmd::fail(ctx, e_ == hipErrorOutOfMemory ? RMD_ERR_OUT_OF_MEMORY : RMD_ERR_HIP, \
+			                 std::string("rmd_scene_create: ") + hipGetErrorString(e_));         \
+		}                                                                                       \
+	} while (0)
+
+	std::vector<rmd::DevGrid> hgrid(n_grids);
+	for (uint32_t gi = 0; gi < n_grids; gi++) {
+		const rmd_grid_desc &g = grids[gi];
+		rmd::DevGrid &d = hgrid[gi];
+		std::memset(&d, 0, sizeof(d));
+		if (!g.cells || !g.mapping_table || !g.tri_pos || !g.tri_nrm || g.n_tris == 0 ||
+		    g.n_cells != (uint64_t)g.resolution[0] * g.resolution[1] * g.resolution[2]) {
+			rmd_scene_destroy(sc);
+			return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: inconsistent grid description");
+		}
+		// validate the CSR-like table so that the kernel's gathers stay in bounds
+		for (uint64_t c = 0; c < g.n_cells; c++) {
+			uint64_t off = g.cells[c];
+			if (off >= g.n_mapping || off + (uint64_t)g.mapping_table[off] >= g.n_mapping) {
+				rmd_scene_destroy(sc);
+				return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table run out of range");
+			}
+			uint32_t cnt = g.mapping_table[off];
+			for (uint32_t k = 1; k <= cnt; k++)
+				if (g.mapping_table[off + k] >= g.n_tris) {
+					rmd_scene_destroy(sc);
+					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: triangle index out of range in mapping_table");
+				}
+		}
+		for (int a = 0; a < 3; a++) {
+			d.bbox_min[a] = g.bbox_min[a], d.bbox_max[a] = g.bbox_max[a], d.cell_size[a] = g.cell_size[a];
+			d.res[a] = g.resolution[a];
+		}
+		d.n_cells = g.n_cells, d.n_tris = g.n_tris;
+		// intersection records: v0, edge1 = v1 - v0, edge2 = v2 - v0 (triangle.rs:16-17, same subtraction, done once)
+		std::vector<double> isect(g.n_tris * 9);
+		for (uint64_t t = 0; t < g.n_tris; t++) {
+			const double *p = g.tri_pos + t * 9;
+			double *q = isect.data() + t * 9;
+			for (int a = 0; a < 3; a++) q[a] = p[a], q[3 + a] = p[3 + a] - p[a], q[6 + a] = p[6 + a] - p[a];
+		}
+		void *p = nullptr;
+		RMD_SCENE_HIP(upload(g.cells, g.n_cells * sizeof(uint32_t), &p));
+		d.cells = (const uint32_t *)p;
+		RMD_SCENE_HIP(upload(g.mapping_table, g.n_mapping * sizeof(uint32_t), &p));
+		d.mapping_table = (const uint32_t *)p;
+		RMD_SCENE_HIP(upload(isect.data(), isect.size() * sizeof(double), &p));
+		d.tri_isect = (const double *)p;
+		RMD_SCENE_HIP(upload(g.tri_pos, g.n_tris * 9 * sizeof(double), &p));
+		d.tri_pos = (const double *)p;
+		RMD_SCENE_HIP(upload(g.tri_nrm, g.n_tris * 9 * sizeof(double), &p));
+		d.tri_nrm = (const double *)p;
+	}
+	void *p = nullptr;
+	RMD_SCENE_HIP(upload(hobj.data(), hobj.size() * sizeof(rmd::DevObject), &p));
+	sc->d_objects = (rmd::DevObject *)p;
+	RMD_SCENE_HIP(upload(hgrid.data(), hgrid.size() * sizeof(rmd::DevGrid), &p));
+	sc->d_grids = (rmd::DevGrid *)p;
+#undef RMD_SCENE_HIP
+	*out = sc;
+	return RMD_OK;
+}
+
+void rmd_scene_destroy(rmd_scene *scene) {
+	if (!scene) return;
+	if (scene->ctx) {
+		(void)hipSetDevice(scene->ctx->device);
+		(void)hipStreamSynchronize(scene->ctx->stream);
+	}
+	for (void *p : scene->owned) (void)hipFree(p);
+	delete scene;
+}
+
+rmd_status rmd_framebuffer_alloc(rmd_context *ctx, uint32_t width, uint32_t height, double **out_dev) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!out_dev || width == 0 || height == 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_alloc: bad argument");
+	size_t bytes = (size_t)width * height * 3 * sizeof(double);
+	RMD_HIP(ctx, hipMalloc((void **)out_dev, bytes));
+	RMD_HIP(ctx, hipMemsetAsync(*out_dev, 0, bytes, ctx->stream));
+	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return RMD_OK;
+}
+rmd_status rmd_framebuffer_free(rmd_context *ctx, double *dev) {
+	if (rmd_status s = bind(ctx)) return s;
+	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RMD_HIP(ctx, hipFree(dev));
+	return RMD_OK;
+}
+rmd_status rmd_framebuffer_zero(rmd_context *ctx, double *dev, size_t n) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!dev) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_zero: null pointer");
+	RMD_HIP(ctx, hipMemsetAsync(dev, 0, n * sizeof(double), ctx->stream));
+	return RMD_OK;
+}
+rmd_status rmd_framebuffer_download(rmd_context *ctx, const double *dev, double *host, size_t n) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!dev || !host) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_download: null pointer");
+	RMD_HIP(ctx, hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return RMD_OK;
+}
+rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *dev, size_t n) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!dev || !host) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_upload: null pointer");
+	RMD_HIP(ctx, hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return RMD_OK;
+}
+
+rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
+                                  const rmd_tile_rect *tiles, uint32_t n_tiles, double *accum_dev) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (rmd_status s = check_render_args(ctx, scene, camera, settings)) return s;
+	if (!accum_dev || (n_tiles && !tiles)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_render_tiles: null tiles/accum pointer");
+	if (rmd_status s = prepare_wave_tiles(ctx, camera, tiles, n_tiles)) return s;
+	rmd::RenderParams P = rmd::make_params(scene, camera, settings);
+	P.n_work = ctx->n_wave_tiles;
+	RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+	RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, P, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev));
+	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+	ctx->timed = true;
+	return RMD_OK;
+}
+
+rmd_status rmd_context_synchronize(rmd_context *ctx) {
+	if (rmd_status s = bind(ctx)) return s;
+	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return RMD_OK;
+}
+
+rmd_status rmd_render_tiles(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
+                            const rmd_tile_rect *tiles, uint32_t n_tiles, double *accum_dev) {
+	if (rmd_status s = rmd_render_tiles_async(ctx, scene, camera, settings, tiles, n_tiles, accum_dev)) return s;
+	return rmd_context_synchronize(ctx);
+}
+
+rmd_status rmd_render_tiles_host(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
+                                 const rmd_tile_rect *tiles, uint32_t n_tiles, double *accum_host) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!camera || !accum_host) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_render_tiles_host: null argument");
+	size_t n = (size_t)camera->backbuffer_width * camera->backbuffer_height * 3;
+	double *dev = nullptr;
+	RMD_HIP(ctx, hipMalloc((void **)&dev, n * sizeof(double)));
+	rmd_status s = rmd_framebuffer_upload(ctx, accum_host, dev, n);
+	if (!s) s = rmd_render_tiles(ctx, scene, camera, settings, tiles, n_tiles, dev);
+	if (!s) s = rmd_framebuffer_download(ctx, dev, accum_host, n);
+	(void)hipFree(dev);
+	return s;
+}
+
+rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!out_ms) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_last_kernel_ms: null pointer");
+	if (!ctx->timed) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_last_kernel_ms: no render has been enqueued on this context");
+	RMD_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+	RMD_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
+	return RMD_OK;
+}
+
+rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32_t width, uint32_t height, uint32_t sample_count,
+                               double exposure, double gamma, uint8_t *out_rgb8_host) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!accum_dev || !out_rgb8_host || width == 0 || height == 0 || sample_count == 0)
+		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_resolve_tonemap: bad argument");
+	size_t n_pixels = (size_t)width * height;
+	uint8_t *d = nullptr;
+	RMD_HIP(ctx, hipMalloc((void **)&d, n_pixels * 3));
+	hipError_t e = rmd::launch_tonemap(ctx->stream, accum_dev, d, n_pixels, (double)sample_count, exposure, 1.0 / gamma);
+	if (e == hipSuccess) e = hipMemcpyAsync(out_rgb8_host, d, n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	RMD_HIP(ctx, e);
+	return RMD_OK;
+}
+
+} // extern "C"

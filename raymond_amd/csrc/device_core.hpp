@@ -1,0 +1,407 @@
+// Device functions of the radiance integrator (gfx950, binary64, no FMA contraction).
+// Each function names the reference code whose arithmetic — operation order included — it performs.
+// Paths are relative to the reference tree (Nyrox/raymond).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.hpp"
+
+#define RMD_DEV __device__ __forceinline__
+
+namespace rmd {
+
+// ---------------------------------------------------------------- cgmath::Vector3<f64> subset
+struct V3 {
+	double x, y, z;
+};
+RMD_DEV V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+RMD_DEV V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
+RMD_DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RMD_DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RMD_DEV V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+RMD_DEV V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+RMD_DEV V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+RMD_DEV V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+RMD_DEV V3 hadamard(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+RMD_DEV double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; } // cgmath: mul_element_wise().sum()
+RMD_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RMD_DEV double length(V3 a) { return sqrt(dot(a, a)); }
+RMD_DEV V3 normalize(V3 a) { return a * (1.0 / length(a)); } // cgmath normalize_to(1.0)
+RMD_DEV double dist(V3 a, V3 b) { return length(b - a); }     // MetricSpace::distance
+
+constexpr double kPi = 3.14159265358979323846; // core/src/math.rs:19
+constexpr double kFMax = 1.7976931348623157e308; // core/src/math.rs:20
+
+// ---------------------------------------------------------------- RNG (include/raymond_hip.h "RNG")
+RMD_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t &o0,
+                           uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+	constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+	for (int round = 0; round < 10; round++) {
+		uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+		uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+		uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+		c0 = n0, c1 = lo1, c2 = n2, c3 = lo0;
+		k0 += W0, k1 += W1;
+	}
+	o0 = c0, o1 = c1, o2 = c2, o3 = c3;
+}
+
+// Per-lane counter RNG: one cached Philox block serves two consecutive draws.
+struct Rng {
+	uint32_t k0, k1, pixel, sample, draw, blk;
+	uint32_t w0, w1, w2, w3;
+	RMD_DEV void init(uint32_t key0, uint32_t key1, uint32_t pixel_, uint32_t sample_) {
+		k0 = key0, k1 = key1, pixel = pixel_, sample = sample_, draw = 0, blk = 0xFFFFFFFFu;
+		w0 = w1 = w2 = w3 = 0;
+	}
+	RMD_DEV double next() {
+		uint32_t b = draw >> 1;
+		if (b != blk) {
+			philox4x32_10(pixel, sample, b, 0u, k0, k1, w0, w1, w2, w3);
+			blk = b;
+		}
+		uint32_t lo = (draw & 1u) ? w2 : w0, hi = (draw & 1u) ? w3 : w1;
+		draw++;
+		uint64_t bits = (((uint64_t)hi << 32) | lo) >> 11;
+		return (double)bits * (1.0 / 9007199254740992.0);
+	}
+};
+
+// ---------------------------------------------------------------- primitives
+// core/src/geometry/primitives/sphere.rs:11-27
+RMD_DEV bool sphere_intersect(V3 center, double radius, V3 ro, V3 rd, double &t_out) {
+	V3 c = center - ro;
+	double t = dot(c, rd);
+	V3 q = c - t * rd;
+	double p = dot(q, q);
+	double r2 = radius * radius;
+	if (p > r2) return false;
+	t -= sqrt(r2 - p);
+	if (t <= 0.0) return false;
+	t_out = t;
+	return true;
+}
+// core/src/geometry/primitives/plane.rs:11-24
+RMD_DEV bool plane_intersect(V3 origin, V3 normal, V3 ro, V3 rd, double &t_out) {
+	double denom = dot(normal, -rd);
+	if (denom > 1e-6) {
+		V3 p0l0 = origin - ro;
+		double t = dot(p0l0, -normal) / denom;
+		if (t >= 0.0) {
+			t_out = t;
+			return true;
+		}
+	}
+	return false;
+}
+// core/src/geometry/primitives/aabb.rs:10-31 (fmin/fmax = Rust f64::min/max NaN rule)
+RMD_DEV bool aabb_intersect(V3 bmin, V3 bmax, V3 ro, V3 rd, double &tmin_out) {
+	double ix = 1.0 / rd.x, iy = 1.0 / rd.y, iz = 1.0 / rd.z;
+	double t1 = (bmin.x - ro.x) * ix, t2 = (bmax.x - ro.x) * ix;
+	double tmin = fmin(t1, t2), tmax = fmax(t1, t2);
+	t1 = (bmin.y - ro.y) * iy, t2 = (bmax.y - ro.y) * iy;
+	tmin = fmax(tmin, fmin(t1, t2)), tmax = fmin(tmax, fmax(t1, t2));
+	t1 = (bmin.z - ro.z) * iz, t2 = (bmax.z - ro.z) * iz;
+	tmin = fmax(tmin, fmin(t1, t2)), tmax = fmin(tmax, fmax(t1, t2));
+	if (!(tmax > fmax(tmin, 0.0))) return false;
+	tmin_out = tmin;
+	return true;
+}
+// core/src/geometry/primitives/triangle.rs:11-44 with edge1/edge2 (:16-17) precomputed at upload
+RMD_DEV bool triangle_intersect(V3 v0, V3 edge1, V3 edge2, V3 ro, V3 rd, double &t_out) {
+	constexpr double EPSILON = 0.00000001;
+	V3 h = cross(rd, edge2);
+	double a = dot(edge1, h);
+	if (a < EPSILON && a > -EPSILON) return false;
+	double f = 1.0 / a;
+	V3 s = ro - v0;
+	double u = f * dot(s, h);
+	if (u < 0.0 || u > 1.0) return false;
+	V3 q = cross(s, edge1);
+	double v = f * dot(rd, q);
+	if (v < 0.0 || u + v > 1.0) return false;
+	double t = f * dot(edge2, q);
+	if (t > EPSILON) {
+		t_out = t;
+		return true;
+	}
+	return false;
+}
+// triangle.rs:47-68
+RMD_DEV double heron_area(V3 a, V3 b, V3 c) {
+	double ab = dist(a, b), ac = dist(a, c), bc = dist(b, c);
+	double s = (ab + ac + bc) / 2.0;
+	return sqrt(s * (s - ab) * (s - ac) * (s - bc));
+}
+RMD_DEV V3 triangle_normal(const double *__restrict__ pos9, const double *__restrict__ nrm9, V3 position) {
+	V3 p0 = ld3(pos9), p1 = ld3(pos9 + 3), p2 = ld3(pos9 + 6);
+	double abc = heron_area(p0, p1, p2);
+	double abp = heron_area(p0, p1, position);
+	double bcp = heron_area(p0, p2, position);
+	double ba = abp / abc, bb = bcp / abc;
+	double bc = 1.0 - (ba + bb);
+	V3 n = (ld3(nrm9 + 6) * ba) + (ld3(nrm9 + 3) * bb) + (ld3(nrm9) * bc);
+	return normalize(n);
+}
+
+// f64 -> i32 as num-traits NumCast does it (truncate; fail on NaN / out of range)
+RMD_DEV bool cast_i32(double v, int32_t &out) {
+	if (!(v > -2147483649.0 && v < 2147483648.0)) return false;
+	out = (int32_t)v;
+	return true;
+}
+
+// core/src/geometry/acc_grid.rs:89-185: 3D-DDA walk, closest hit of the first cell that yields any hit.
+// Where the reference would panic (a failed i32 cast, :94,:98,:102) this reports a miss.
+RMD_DEV bool grid_intersect(const DevGrid &g, V3 ro, V3 rd, double &t_out, uint32_t &tri_out) {
+	V3 bmin = ld3(g.bbox_min);
+	double t_outer;
+	if (!aabb_intersect(bmin, ld3(g.bbox_max), ro, rd, t_outer)) return false;
+	V3 cs = ld3(g.cell_size);
+	V3 start = ro - bmin;
+	int32_t cx, cy, cz;
+	if (!cast_i32(start.x / cs.x, cx) || !cast_i32(start.y / cs.y, cy) || !cast_i32(start.z / cs.z, cz)) return false;
+	if (cx < 0 || cy < 0 || cz < 0) {
+		V3 outer_pos = ro + rd * t_outer;
+		start = outer_pos - bmin;
+		if (!cast_i32(start.x / cs.x, cx) || !cast_i32(start.y / cs.y, cy) || !cast_i32(start.z / cs.z, cz)) return false;
+	}
+	if (rd.x != rd.x || rd.y != rd.y || rd.z != rd.z) return false; // signum(NaN).cast::<i32>() panics
+	const int32_t sx = signbit(rd.x) ? -1 : 1, sy = signbit(rd.y) ? -1 : 1, sz = signbit(rd.z) ? -1 : 1;
+
+	const double t_delta_x = (rd.x < 0.0 ? -cs.x : cs.x) / rd.x;
+	const double t_delta_y = (rd.y < 0.0 ? -cs.y : cs.y) / rd.y;
+	const double t_delta_z = (rd.z < 0.0 ? -cs.z : cs.z) / rd.z;
+	double t_max_x = (((double)(cx + (rd.x < 0.0 ? 0 : 1)) * cs.x) - start.x) / rd.x;
+	double t_max_y = (((double)(cy + (rd.y < 0.0 ? 0 : 1)) * cs.y) - start.y) / rd.y;
+	double t_max_z = (((double)(cz + (rd.z < 0.0 ? 0 : 1)) * cs.z) - start.z) / rd.z;
+
+	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
+	const uint32_t *__restrict__ cells = g.cells;
+	const uint32_t *__restrict__ map = g.mapping_table;
+	const double *__restrict__ tris = g.tri_isect;
+	for (;;) {
+		// `as usize` sign-extends, the index arithmetic wraps (release build); Q5: res.z where res.y is meant
+		uint64_t idx = (uint64_t)(int64_t)cx + g.res[0] * ((uint64_t)(int64_t)cy + (uint64_t)(int64_t)cz * g.res[2]);
+		if (idx >= g.n_cells) return false;
+		uint32_t cell = cells[idx];
+		uint32_t count = map[cell];
+		double closest = 5712515.0;
+		bool any = false;
+		uint32_t best_tri = 0;
+		for (uint32_t i = 1; i <= count; i++) {
+			uint32_t ti = map[cell + i];
+			const double *tp = tris + (size_t)ti * 9;
+			double t;
+			if (triangle_intersect(ld3(tp), ld3(tp + 3), ld3(tp + 6), ro, rd, t)) {
+				if (t < closest) {
+					closest = t;
+					best_tri = ti;
+					any = true;
+				}
+			}
+		}
+		if (any) {
+			t_out = closest;
+			tri_out = best_tri;
+			return true;
+		}
+		if (t_max_x < t_max_y) {
+			if (t_max_x < t_max_z) {
+				cx += sx;
+				if (cx >= rx || cx < 0) return false;
+				t_max_x += t_delta_x;
+			} else {
+				cz += sz;
+				if (cz >= rz || cz < 0) return false;
+				t_max_z += t_delta_z;
+			}
+		} else {
+			if (t_max_y < t_max_z) {
+				cy += sy;
+				if (cy >= ry || cy < 0) return false;
+				t_max_y += t_delta_y;
+			} else {
+				cz += sz;
+				if (cz >= rz || cz < 0) return false;
+				t_max_z += t_delta_z;
+			}
+		}
+	}
+}
+
+// core/src/scene.rs:54-74: linear closest hit; strict '<' keeps the first object on ties.
+// `objs` is indexed uniformly across the wave, so the fetches are scalar loads.
+RMD_DEV int scene_intersect(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, V3 ro,
+                            V3 rd, double &t_best, uint32_t &sub_best) {
+	double closest = kFMax;
+	int best = -1;
+	uint32_t sub = 0;
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const DevObject &o = objs[i];
+		double t;
+		uint32_t tri = 0;
+		bool hit;
+		if (o.geometry_kind == 0u) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
+		else if (o.geometry_kind == 1u) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
+		else hit = grid_intersect(grids[o.grid_index], ro, rd, t, tri);
+		if (hit) {
+			if (t < closest) {
+				closest = t;
+				best = (int)i;
+				sub = tri;
+			}
+		}
+	}
+	t_best = closest;
+	sub_best = sub;
+	return best;
+}
+
+// ---------------------------------------------------------------- BRDF + samplers (src/trace.rs:362-416)
+RMD_DEV double lerp(double mn, double mx, double a) { return mn + a * (mx - mn); } // :392-394
+// :362-370 — NdotH.powf(2.0) is x*x after LLVM's unconditional pow(x, 2.0) fold
+RMD_DEV double ggx_distribution(V3 n, V3 h, double roughness) {
+	double a2 = roughness * roughness;
+	double ndh = dot(n, h);
+	double den = (ndh * ndh) * (a2 - 1.0) + 1.0;
+	den = fmax(kPi * den * den, 1e-7);
+	return a2 / den;
+}
+// :372-378
+RMD_DEV double geometry_schlick_ggx(V3 n, V3 v, double r) {
+	double num = fmax(dot(n, v), 0.0);
+	double k = (r * r) / 8.0;
+	return num / (num * (1.0 - k) + k);
+}
+// :380-382
+RMD_DEV double geometry_smith(V3 n, V3 v, V3 l, double r) { return geometry_schlick_ggx(n, v, r) * geometry_schlick_ggx(n, l, r); }
+// :384-386
+RMD_DEV V3 fresnel_schlick(double cos_theta, V3 f0) { return f0 + (mk(1.0, 1.0, 1.0) - f0) * pow(1.0 - cos_theta, 5.0); }
+// :408-416
+RMD_DEV void onb(V3 n, V3 &t, V3 &b) {
+	double sign = n.z > 0.0 ? 1.0 : -1.0;
+	double a = -1.0 / (sign + n.z);
+	double bb = n.x * n.y * a;
+	t = mk(1.0 + sign * n.x * n.x * a, sign * bb, -sign * n.x);
+	b = mk(bb, sign + n.y * n.y * a, -n.y);
+}
+// cgmath Matrix3::from_cols(c0, c1, c2) * v
+RMD_DEV V3 mat3_mul(V3 c0, V3 c1, V3 c2, V3 v) {
+	return mk((c0.x * v.x + c1.x * v.y) + c2.x * v.z, (c0.y * v.x + c1.y * v.y) + c2.y * v.z, (c0.z * v.x + c1.z * v.y) + c2.z * v.z);
+}
+// :396-406
+RMD_DEV void cosine_hemisphere(double r1, double r2, V3 &dir, double &pdf) {
+	double sr = sqrt(r1);
+	double theta = acos(sr);
+	double phi = 2.0 * kPi * r2;
+	pdf = sr;
+	double st = sin(theta), ct = cos(theta);
+	dir = mk(st * cos(phi), ct, st * sin(phi));
+}
+// :286-296
+RMD_DEV V3 importance_sample_ggx(V3 reflect, double roughness, double r1, double r2) {
+	double a = roughness * roughness;
+	double phi = 2.0 * kPi * r1;
+	double theta = a * sqrt(r2 / (1.0 - r2));
+	double st = sin(theta), ct = cos(theta);
+	V3 h = mk(st * cos(phi), ct, st * sin(phi));
+	V3 tg, bt;
+	onb(reflect, tg, bt);
+	return normalize(mat3_mul(tg, reflect, bt, h));
+}
+
+// One evaluation of the shading half of trace() (src/trace.rs:256-319) for a non-emissive hit.
+// Everything the reference computes after its recursive call depends only on values known before
+// it, so the weights are produced here and applied when the path unwinds:
+//   diffuse  (:281-282): out = ((A (.) radiance) * cos) / d1           A = diffuse_part (.) color, d1 = prob_d * pdf
+//   specular (:315-318): out = (((A (.) radiance) * cos) / d1) / d2    A = specular, d1 = 1 - prob_d, d2 = pdf
+struct Bounce {
+	V3 A;
+	double cosv, d1, d2;
+	bool specular;
+	V3 next_origin, next_dir;
+};
+RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double metal, V3 cam_pos, Rng &rng) {
+	Bounce out;
+	V3 view = normalize(cam_pos - frag); // :256
+	V3 f0 = mk(lerp(0.04, color.x, metal), lerp(0.04, color.y, metal), lerp(0.04, color.z, metal)); // :257-258
+	double r = rng.next(); // :260
+	double prob_d = lerp(0.5, 0.0, metal); // :263
+	if (r < prob_d) {
+		double r1 = rng.next(), r2 = rng.next();
+		V3 lt, lb;
+		onb(normal, lt, lb); // :261-262
+		V3 local;
+		double pdf;
+		cosine_hemisphere(r1, r2, local, pdf);
+		V3 sw = normalize(mat3_mul(lt, normal, lb, local)); // :266
+		out.next_origin = frag + normal * 0.00001;          // :269
+		out.next_dir = sw;
+		out.cosv = fmax(dot(normal, sw), 0.0);                       // :275
+		V3 halfway = normalize(sw + view);                           // :276
+		V3 fres = fresnel_schlick(fmax(dot(halfway, view), 0.0), f0); // :277
+		V3 diffuse_part = (mk(1.0, 1.0, 1.0) - fres) * (1.0 - metal); // :279-280
+		out.A = hadamard(diffuse_part, color);
+		out.d1 = prob_d * pdf;
+		out.d2 = 1.0;
+		out.specular = false;
+	} else {
+		V3 reflect = normalize(-view - 2.0 * (-dot(view, normal) * normal)); // :285
+		double r1 = rng.next(), r2 = rng.next();                             // :287-288
+		V3 sw = importance_sample_ggx(reflect, roughness, r1, r2);
+		out.next_origin = frag + normal * 0.0001; // :300
+		out.next_dir = sw;
+		double cos_theta = dot(normal, sw); // :306
+		V3 light_dir = normalize(sw);       // :307
+		V3 halfway = normalize(light_dir + view);
+		V3 F = fresnel_schlick(dot(halfway, view), f0);
+		double D = ggx_distribution(normal, halfway, roughness);
+		double G = geometry_smith(normal, view, sw, roughness);
+		V3 nominator = (D * G) * F;
+		double denominator = 4.0 * dot(normal, view) * cos_theta + 0.001;
+		out.A = nominator / denominator;
+		out.cosv = cos_theta;
+		out.d1 = 1.0 - prob_d;
+		out.d2 = (D * dot(normal, halfway)) / (4.0 * dot(halfway, view)) + 0.0001; // :317
+		out.specular = true;
+	}
+	return out;
+}
+
+// ---------------------------------------------------------------- ray generation (src/trace.rs:322-360)
+RMD_DEV void primary_ray(const RenderParams &P, uint32_t xi, uint32_t yi, double u0, double u1, V3 &ro, V3 &rd) {
+	double x = (double)xi + (u0 - 0.5);
+	double y = (double)yi + (u1 - 0.5);
+	double px = (2.0 * ((x + 0.5) / P.width) - 1.0) * P.tan_half_fov * P.aspect;
+	double py = (1.0 - 2.0 * ((y + 0.5) / P.height)) * P.tan_half_fov;
+	ro = ld3(P.cam_pos);
+	rd = normalize(mk(px, py, 1.0));
+}
+// :335-360.  Returns false where the reference's unwrap() on the focal-plane hit would panic.
+RMD_DEV bool primary_ray_dof(const RenderParams &P, uint32_t xi, uint32_t yi, Rng &rng, V3 &ro, V3 &rd) {
+	double u0 = rng.next(), u1 = rng.next();
+	V3 po, pd;
+	primary_ray(P, xi, yi, u0, u1, po, pd);
+	V3 pos = ld3(P.cam_pos);
+	V3 start = pos;
+	// unbounded rejection loop in the reference; 4096 rounds at acceptance pi/4 is never reached,
+	// and gives every wave a guaranteed exit.
+	for (int guard = 0; guard < 4096; guard++) {
+		double r1 = rng.next() * 2.0 - 1.0;
+		double r2 = rng.next() * 2.0 - 1.0;
+		start = mk(pos.x + r1 * P.aperture_radius, pos.y + r2 * P.aperture_radius, pos.z);
+		if (dist(start, pos) < P.aperture_radius) break;
+	}
+	V3 fp_origin = pos + mk(0.0, 0.0, 1.0) * P.focal_length;
+	double t;
+	if (!plane_intersect(fp_origin, mk(0.0, 0.0, -1.0), po, pd, t)) return false;
+	V3 end = pos + t * pd;
+	ro = start;
+	rd = normalize(end - start);
+	return true;
+}
+
+} // namespace rmd

@@ -1,0 +1,72 @@
+// Device-resident scene layout shared by the kernels (kernels.hip) and the C-ABI host code (api.cpp).
+// HBM layout is described in DESIGN.md §"Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+namespace rmd {
+
+// One scene::Object (reference core/src/scene.rs:33-37), flattened.  128 bytes, 16-byte aligned so the
+// uniform object loop can fetch it with wide scalar loads and the per-lane post-hit lookup from the LDS
+// copy is conflict-light.
+struct alignas(16) DevObject {
+	uint32_t geometry_kind; // RMD_GEOM_*
+	uint32_t grid_index;
+	uint32_t material_kind; // RMD_MAT_*
+	uint32_t _pad0;
+	double origin[3]; // plane origin / sphere centre
+	double radius;
+	double normal[3]; // plane normal
+	double roughness;
+	double color[3]; // Diffuse/Metal colour, Emission radiance
+	double metalness; // 0.0 Diffuse, 1.0 Metal (src/trace.rs:248-249)
+	double _pad1[2];
+};
+static_assert(sizeof(DevObject) == 128, "DevObject layout");
+
+// One AccGrid (reference core/src/geometry/acc_grid.rs:27-33).
+struct alignas(16) DevGrid {
+	double bbox_min[3];
+	double bbox_max[3];
+	double cell_size[3];
+	uint64_t res[3];
+	uint64_t n_cells;
+	const uint32_t *cells;         // n_cells offsets into mapping_table
+	const uint32_t *mapping_table; // [count, idx...] runs
+	const double *tri_isect;       // n_tris * 9: v0, edge1 = v1 - v0, edge2 = v2 - v0 (triangle.rs:16-17 hoisted to upload)
+	const double *tri_pos;         // n_tris * 9: v0 v1 v2 (Heron normal, triangle.rs:47-68)
+	const double *tri_nrm;         // n_tris * 9: n0 n1 n2
+	uint64_t n_tris;
+};
+
+// 8x8-pixel wave tile: one wavefront, lane = pixel (lane & 7, lane >> 3).
+struct WaveTile {
+	uint16_t x0, y0;
+	uint8_t w, h; // 1..8
+	uint16_t _pad;
+};
+static_assert(sizeof(WaveTile) == 8, "WaveTile layout");
+
+// Loop-invariant camera terms of generate_primary_ray (src/trace.rs:322-333), evaluated once on the host.
+struct RenderParams {
+	double cam_pos[3];
+	double width, height;  // backbuffer size as f64 (:323-324)
+	double aspect;         // width / height (:325)
+	double tan_half_fov;   // tan(fov_vert / 2 * PI / 180) (:329-330)
+	double focal_length;
+	double aperture_radius;
+	uint32_t W, H;
+	uint32_t bounce_limit;
+	uint32_t sample_begin;
+	uint32_t sample_count;
+	uint32_t n_objects;
+	uint32_t key0, key1; // Philox key = seed lo/hi
+	uint32_t n_work;     // wave tiles (tile mode) or list entries (list mode)
+	uint32_t use_dof;
+};
+
+// List mode (probe): one lane per explicit (x, y, sample).
+struct ListWork {
+	uint32_t x, y, sample, _pad;
+};
+
+} // namespace rmd

@@ -1,0 +1,42 @@
+// Library-internal declarations shared by api.cpp, probe.cpp, comm.cpp and grid_build.cpp.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/raymond_hip.h"
+
+#ifdef RMD_WITH_HIP
+#include <hip/hip_runtime_api.h>
+
+#include "device_types.hpp"
+
+struct rmd_context {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool owns_stream = false;
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	bool timed = false;
+	std::string last_error;
+	// cached wave-tile table (device) for the rect list of the previous call
+	std::vector<rmd_tile_rect> cached_rects;
+	uint32_t cached_W = 0, cached_H = 0;
+	rmd::WaveTile *d_wave_tiles = nullptr;
+	uint32_t n_wave_tiles = 0;
+	size_t wave_tiles_capacity = 0;
+};
+
+struct rmd_scene {
+	rmd_context *ctx = nullptr;
+	uint32_t n_objects = 0, n_grids = 0;
+	rmd::DevObject *d_objects = nullptr;
+	rmd::DevGrid *d_grids = nullptr;
+	std::vector<void *> owned; // every device allocation of this scene
+};
+#endif
+
+namespace rmd {
+// Records `text` as the last error of `ctx` (or of the calling thread when ctx is null) and returns `status`.
+rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text);
+} // namespace rmd

@@ -1,0 +1,336 @@
+// HIP kernels of the radiance integrator for gfx950 (CDNA4).
+//
+// render_kernel<false> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel.
+//   Each lane runs the reference's per-pixel loop (src/trace.rs:197-205) for `sample_count`
+//   consecutive samples as an iterative state machine: a lane whose path ends regenerates the next
+//   sample's primary ray in place (in-lane path regeneration), so the wave stays full until the
+//   last samples.  trace()'s recursion (src/trace.rs:232-320) becomes a per-lane LDS stack of
+//   bounce weights that is unwound in the reference's evaluation order when the path terminates.
+//   The object table is staged into LDS once per wave (coalesced); the uniform closest-hit loop
+//   reads it through scalar loads, the divergent post-hit lookup reads the LDS copy.
+//   MFMA is not used: there is no dense contraction anywhere on this path.
+// render_kernel<true>  — the same code driven by an explicit (x, y, sample) list, one sample per
+//   lane, radiance written out per entry (per-sample parity probe).
+// probe_* — device-function known-answer probes for the parity tests.
+#include <hip/hip_runtime.h>
+
+#include "device_core.hpp"
+#include "launch.hpp"
+
+namespace rmd {
+
+// LDS stack slot (level, comp, lane), 6 doubles per level (A.xyz, cos, d1, d2): consecutive lanes hit consecutive 8-byte words, so every
+// access is bank-conflict free whatever level each lane is at (levels differ by multiples of 512 B).
+RMD_DEV int stack_slot(uint32_t level, int comp, uint32_t lane) { return (int)((level * 6u + (uint32_t)comp) * 64u + lane); }
+
+// Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs; giving each XCD a
+// contiguous run of wave tiles keeps neighbouring tiles (which walk the same grid cells and
+// triangles) behind one L2.  Bijective for any grid size; affects speed only.
+RMD_DEV uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+	uint32_t xcd = b & 7u, slot = b >> 3;
+	uint32_t q = nb >> 3, r = nb & 7u;
+	uint32_t start = xcd * q + (xcd < r ? xcd : r);
+	return start + slot;
+}
+
+template <bool LIST>
+__global__ __launch_bounds__(64) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
+                                                    const DevGrid *__restrict__ grids, const void *__restrict__ work,
+                                                    double *__restrict__ out, int32_t *__restrict__ path_obj,
+                                                    uint32_t *__restrict__ path_sub) {
+	extern __shared__ __align__(16) unsigned char smem[];
+	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
+	double *stack = reinterpret_cast<double *>(smem + (size_t)P.n_objects * sizeof(DevObject));
+	const uint32_t lane = threadIdx.x;
+
+	// stage the object table: 16 doubles per object, coalesced
+	{
+		const double *src = reinterpret_cast<const double *>(objs);
+		double *dst = reinterpret_cast<double *>(lobjs);
+		for (uint32_t i = lane; i < P.n_objects * 16u; i += 64u) dst[i] = src[i];
+	}
+	__syncthreads();
+
+	uint32_t x, y, s, s_end;
+	bool alive;
+	size_t out_index;
+	if (LIST) {
+		uint32_t idx = blockIdx.x * 64u + lane;
+		alive = idx < P.n_work;
+		ListWork w = reinterpret_cast<const ListWork *>(work)[alive ? idx : 0];
+		x = w.x, y = w.y, s = w.sample, s_end = w.sample + 1u;
+		out_index = (size_t)idx * 3;
+	} else {
+		uint32_t wt = xcd_remap(blockIdx.x, gridDim.x);
+		WaveTile t = reinterpret_cast<const WaveTile *>(work)[wt];
+		uint32_t lx = lane & 7u, ly = lane >> 3;
+		alive = lx < t.w && ly < t.h && P.sample_count > 0u;
+		x = t.x0 + lx, y = t.y0 + ly;
+		s = P.sample_begin, s_end = P.sample_begin + P.sample_count;
+		out_index = ((size_t)x + (size_t)y * P.W) * 3;
+	}
+	const uint32_t pixel = y * P.W + x;
+	const bool writes = alive;
+
+	V3 acc = mk(0.0, 0.0, 0.0);
+	if (!LIST && alive) acc = ld3(out + out_index);
+
+	const V3 cam_pos = ld3(P.cam_pos);
+	Rng rng;
+	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+	uint32_t depth = 1;      // depth argument of the trace() call being evaluated
+	uint32_t specmask = 0;   // bit l: stack level l is a specular bounce
+	uint32_t path_len = 0;
+	bool fresh = true;
+
+	while (alive) {
+		bool terminal = false;
+		V3 L = mk(0.0, 0.0, 0.0);
+		if (fresh) {
+			// src/trace.rs:199 — primary ray of sample s
+			rng.init(P.key0, P.key1, pixel, s);
+			bool ok = true;
+			if (P.use_dof) {
+				ok = primary_ray_dof(P, x, y, rng, ro, rd);
+			} else {
+				double u0 = rng.next(), u1 = rng.next();
+				primary_ray(P, x, y, u0, u1, ro, rd);
+			}
+			depth = 1;
+			specmask = 0;
+			fresh = false;
+			if (!ok) terminal = true; // reference panics here; the sample contributes zero
+		}
+		if (!terminal) {
+			// src/trace.rs:239
+			double t;
+			uint32_t sub;
+			int oi = scene_intersect(objs, P.n_objects, grids, ro, rd, t, sub);
+			if (LIST && path_obj) {
+				size_t pi = (size_t)(blockIdx.x * 64u + lane) * (RMD_PATH_STRIDE) + path_len;
+				path_obj[pi] = oi;
+				path_sub[pi] = oi >= 0 ? sub : 0u;
+				path_len++;
+			}
+			if (oi < 0) {
+				terminal = true; // :242 miss -> radiance 0
+			} else {
+				const DevObject &o = lobjs[oi];
+				V3 frag = ro + rd * t; // :246
+				if (o.material_kind == 2u) {
+					L = ld3(o.color); // :250-252 Emission
+					terminal = true;
+				} else {
+					V3 normal;
+					if (o.geometry_kind == 0u) normal = ld3(o.normal);                                // plane.rs:28-32
+					else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin)); // sphere.rs:31-35
+					else {
+						const DevGrid &g = grids[o.grid_index];
+						normal = triangle_normal(g.tri_pos + (size_t)sub * 9, g.tri_nrm + (size_t)sub * 9, frag); // acc_grid.rs:85-87
+					}
+					Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
+					const uint32_t lvl = depth - 1u;
+					stack[stack_slot(lvl, 0, lane)] = b.A.x;
+					stack[stack_slot(lvl, 1, lane)] = b.A.y;
+					stack[stack_slot(lvl, 2, lane)] = b.A.z;
+					stack[stack_slot(lvl, 3, lane)] = b.cosv;
+					stack[stack_slot(lvl, 4, lane)] = b.d1;
+					stack[stack_slot(lvl, 5, lane)] = b.d2;
+					specmask = b.specular ? (specmask | (1u << lvl)) : (specmask & ~(1u << lvl));
+					ro = b.next_origin, rd = b.next_dir;
+					depth++;
+					if (depth > P.bounce_limit) terminal = true; // :235-237: the recursive call returns 0 at once
+				}
+			}
+		}
+		if (terminal) {
+			// unwind the recursion: levels depth-2 .. 0, each applying its bounce's return expression
+			for (int lvl = (int)depth - 2; lvl >= 0; lvl--) {
+				V3 A = mk(stack[stack_slot(lvl, 0, lane)], stack[stack_slot(lvl, 1, lane)], stack[stack_slot(lvl, 2, lane)]);
+				double cosv = stack[stack_slot(lvl, 3, lane)];
+				double d1 = stack[stack_slot(lvl, 4, lane)];
+				L = (hadamard(A, L) * cosv) / d1;
+				if (specmask & (1u << lvl)) L = L / stack[stack_slot(lvl, 5, lane)];
+			}
+			acc = acc + L; // src/trace.rs:203
+			s++;
+			fresh = true;
+			if (s == s_end) alive = false;
+		}
+	}
+
+	if (writes) {
+		out[out_index + 0] = acc.x;
+		out[out_index + 1] = acc.y;
+		out[out_index + 2] = acc.z;
+	}
+}
+
+// ---------------------------------------------------------------- resolve + tone-map (cli_old/src/main.rs:161-181, src/trace.rs:95)
+__global__ __launch_bounds__(256) void tonemap_kernel(const double *__restrict__ accum, uint8_t *__restrict__ rgb8, size_t n_pixels,
+                                                       double sample_count, double exposure, double inv_gamma) {
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_pixels) return;
+	double v[3];
+	bool ok = true;
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		double p = accum[i * 3 + c] / sample_count; // TaskHandle::await, src/trace.rs:95
+		double tm = 1.0 - exp(p * -1.0 * exposure);
+		tm = pow(tm, inv_gamma);
+		v[c] = tm * 255.0;
+		ok = ok && (v[c] > -1.0 && v[c] < 256.0);
+	}
+	// Vector3<f64>.cast::<u8>() is None if any channel is NaN / out of range: the pixel then stays (0,0,0)
+#pragma unroll
+	for (int c = 0; c < 3; c++) rgb8[i * 3 + c] = ok ? (uint8_t)v[c] : (uint8_t)0;
+}
+
+// ---------------------------------------------------------------- probes
+__global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const double *__restrict__ in, int in_stride,
+                                                   double *__restrict__ out, int out_stride, RenderParams P) {
+	uint32_t i = blockIdx.x * 64u + threadIdx.x;
+	if (i >= n) return;
+	const double *a = in + (size_t)i * in_stride;
+	double *o = out + (size_t)i * out_stride;
+	switch (op) {
+	case PROBE_PHILOX: {
+		uint32_t w0, w1, w2, w3;
+		philox4x32_10((uint32_t)a[0], (uint32_t)a[1], (uint32_t)a[2], (uint32_t)a[3], (uint32_t)a[4], (uint32_t)a[5], w0, w1, w2, w3);
+		o[0] = w0, o[1] = w1, o[2] = w2, o[3] = w3;
+	} break;
+	case PROBE_UNIFORM: {
+		Rng r;
+		r.init((uint32_t)a[0], (uint32_t)a[1], (uint32_t)a[2], (uint32_t)a[3]);
+		r.draw = (uint32_t)a[4];
+		o[0] = r.next();
+	} break;
+	case PROBE_SPHERE_INTERSECT: {
+		double t = 0.0;
+		bool h = sphere_intersect(ld3(a), a[3], ld3(a + 4), ld3(a + 7), t);
+		o[0] = h, o[1] = h ? t : 0.0;
+	} break;
+	case PROBE_SPHERE_NORMAL: {
+		V3 frag = ld3(a + 4) + ld3(a + 7) * a[10];
+		V3 nn = normalize(frag - ld3(a));
+		o[0] = nn.x, o[1] = nn.y, o[2] = nn.z;
+	} break;
+	case PROBE_PLANE_INTERSECT: {
+		double t = 0.0;
+		bool h = plane_intersect(ld3(a), ld3(a + 3), ld3(a + 6), ld3(a + 9), t);
+		o[0] = h, o[1] = h ? t : 0.0;
+	} break;
+	case PROBE_AABB_INTERSECT: {
+		double t = 0.0;
+		bool h = aabb_intersect(ld3(a), ld3(a + 3), ld3(a + 6), ld3(a + 9), t);
+		o[0] = h, o[1] = h ? t : 0.0;
+	} break;
+	case PROBE_TRIANGLE_INTERSECT: {
+		V3 p0 = ld3(a), p1 = ld3(a + 3), p2 = ld3(a + 6);
+		double t = 0.0;
+		bool h = triangle_intersect(p0, p1 - p0, p2 - p0, ld3(a + 9), ld3(a + 12), t);
+		o[0] = h, o[1] = h ? t : 0.0;
+	} break;
+	case PROBE_TRIANGLE_NORMAL: {
+		V3 frag = ld3(a + 18) + ld3(a + 21) * a[24];
+		V3 nn = triangle_normal(a, a + 9, frag);
+		o[0] = nn.x, o[1] = nn.y, o[2] = nn.z;
+	} break;
+	case PROBE_ONB: {
+		V3 t, b;
+		onb(ld3(a), t, b);
+		o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = b.x, o[4] = b.y, o[5] = b.z;
+	} break;
+	case PROBE_COSINE_HEMISPHERE: {
+		V3 d;
+		double pdf;
+		cosine_hemisphere(a[0], a[1], d, pdf);
+		o[0] = d.x, o[1] = d.y, o[2] = d.z, o[3] = pdf;
+	} break;
+	case PROBE_SAMPLE_GGX: {
+		V3 d = importance_sample_ggx(ld3(a), a[3], a[4], a[5]);
+		o[0] = d.x, o[1] = d.y, o[2] = d.z;
+	} break;
+	case PROBE_GGX_DISTRIBUTION: o[0] = ggx_distribution(ld3(a), ld3(a + 3), a[6]); break;
+	case PROBE_GEOMETRY_SMITH: o[0] = geometry_smith(ld3(a), ld3(a + 3), ld3(a + 6), a[9]); break;
+	case PROBE_FRESNEL_SCHLICK: {
+		V3 f = fresnel_schlick(a[0], ld3(a + 1));
+		o[0] = f.x, o[1] = f.y, o[2] = f.z;
+	} break;
+	case PROBE_PRIMARY_RAY: {
+		V3 ro, rd;
+		primary_ray(P, (uint32_t)a[0], (uint32_t)a[1], a[2], a[3], ro, rd);
+		o[0] = ro.x, o[1] = ro.y, o[2] = ro.z, o[3] = rd.x, o[4] = rd.y, o[5] = rd.z;
+	} break;
+	default: break;
+	}
+}
+
+// mode 0: Scene::intersect -> (obj, t, sub);  mode 1: AccGrid::intersects on grid `g` -> (hit, t, tri)
+__global__ __launch_bounds__(64) void probe_scene_kernel(int mode, uint32_t g, uint32_t n, const DevObject *__restrict__ objs,
+                                                         uint32_t n_objects, const DevGrid *__restrict__ grids,
+                                                         const double *__restrict__ rays, double *__restrict__ out) {
+	uint32_t i = blockIdx.x * 64u + threadIdx.x;
+	if (i >= n) return;
+	V3 ro = ld3(rays + (size_t)i * 6), rd = ld3(rays + (size_t)i * 6 + 3);
+	double *o = out + (size_t)i * 3;
+	if (mode == 0) {
+		double t;
+		uint32_t sub;
+		int oi = scene_intersect(objs, n_objects, grids, ro, rd, t, sub);
+		o[0] = oi, o[1] = oi >= 0 ? t : 0.0, o[2] = oi >= 0 ? sub : 0u;
+	} else {
+		double t = 0.0;
+		uint32_t tri = 0;
+		bool h = grid_intersect(grids[g], ro, rd, t, tri);
+		o[0] = h, o[1] = h ? t : 0.0, o[2] = h ? tri : 0u;
+	}
+}
+
+// ---------------------------------------------------------------- launchers
+size_t render_lds_bytes(uint32_t n_objects, uint32_t bounce_limit) {
+	return (size_t)n_objects * sizeof(DevObject) + (size_t)bounce_limit * 6u * 64u * sizeof(double);
+}
+
+hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
+                               const WaveTile *wave_tiles, double *accum) {
+	if (P.n_work == 0) return hipSuccess;
+	size_t lds = render_lds_bytes(P.n_objects, P.bounce_limit);
+	hipLaunchKernelGGL(render_kernel<false>, dim3(P.n_work), dim3(64), lds, stream, P, objs, grids, (const void *)wave_tiles, accum,
+	                   (int32_t *)nullptr, (uint32_t *)nullptr);
+	return hipGetLastError();
+}
+
+hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
+                              const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub) {
+	if (P.n_work == 0) return hipSuccess;
+	size_t lds = render_lds_bytes(P.n_objects, P.bounce_limit);
+	hipLaunchKernelGGL(render_kernel<true>, dim3((P.n_work + 63u) / 64u), dim3(64), lds, stream, P, objs, grids, (const void *)list,
+	                   rgb_out, path_obj, path_sub);
+	return hipGetLastError();
+}
+
+hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8, size_t n, double sample_count, double exposure,
+                          double inv_gamma) {
+	// n = number of pixels
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, accum, rgb8, n, sample_count, exposure,
+	                   inv_gamma);
+	return hipGetLastError();
+}
+
+hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in, int in_stride, double *out, int out_stride,
+                        const RenderParams &P) {
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(probe_kernel, dim3((n + 63u) / 64u), dim3(64), 0, stream, op, n, in, in_stride, out, out_stride, P);
+	return hipGetLastError();
+}
+
+hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,
+                              const DevGrid *grids, const double *rays, double *out) {
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(probe_scene_kernel, dim3((n + 63u) / 64u), dim3(64), 0, stream, mode, g, n, objs, n_objects, grids, rays, out);
+	return hipGetLastError();
+}
+
+} // namespace rmd

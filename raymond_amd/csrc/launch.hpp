@@ -1,0 +1,45 @@
+// Host-callable launchers of kernels.hip (internal to the library).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "device_types.hpp"
+
+// entries per lane in the list-mode path record: one per trace() depth, bounce_limit <= 16
+#define RMD_PATH_STRIDE 17
+
+namespace rmd {
+
+enum ProbeOp {
+	PROBE_PHILOX = 0,
+	PROBE_UNIFORM,
+	PROBE_SPHERE_INTERSECT,
+	PROBE_SPHERE_NORMAL,
+	PROBE_PLANE_INTERSECT,
+	PROBE_AABB_INTERSECT,
+	PROBE_TRIANGLE_INTERSECT,
+	PROBE_TRIANGLE_NORMAL,
+	PROBE_ONB,
+	PROBE_COSINE_HEMISPHERE,
+	PROBE_SAMPLE_GGX,
+	PROBE_GGX_DISTRIBUTION,
+	PROBE_GEOMETRY_SMITH,
+	PROBE_FRESNEL_SCHLICK,
+	PROBE_PRIMARY_RAY,
+	PROBE_OP_COUNT
+};
+
+size_t render_lds_bytes(uint32_t n_objects, uint32_t bounce_limit);
+hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
+                               const WaveTile *wave_tiles, double *accum);
+hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
+                              const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub);
+hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8, size_t n_pixels, double sample_count,
+                          double exposure, double inv_gamma);
+hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in, int in_stride, double *out, int out_stride,
+                        const RenderParams &P);
+hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,
+                              const DevGrid *grids, const double *rays, double *out);
+
+} // namespace rmd

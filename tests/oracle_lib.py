@@ -1,0 +1,166 @@
+"""ctypes loader for oracle/liboracle.so — the CPU restatement of the reference path.
+
+Test infrastructure: imported only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Never imported by raymond_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raymond_amd import abi
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(_ROOT, "oracle")
+ORACLE_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+_P = C.POINTER
+_vp = C.c_void_p
+_sz = C.c_size_t
+_SIGS = {
+    "orc_philox4x32_10": (None, [_vp, _vp, _vp]),
+    "orc_uniform": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "orc_sphere_intersect": (None, [_sz, _vp, _vp, _vp, _vp]),
+    "orc_sphere_normal": (None, [_sz, _vp, _vp, _vp, _vp]),
+    "orc_plane_intersect": (None, [_sz, _vp, _vp, _vp, _vp]),
+    "orc_aabb_intersect": (None, [_sz, _vp, _vp, _vp, _vp]),
+    "orc_triangle_intersect": (None, [_sz, _vp, _vp, _vp, _vp]),
+    "orc_triangle_normal": (None, [_sz, _vp, _vp, _vp, _vp, _vp]),
+    "orc_onb": (None, [_sz, _vp, _vp, _vp]),
+    "orc_cosine_hemisphere": (None, [_sz, _vp, _vp, _vp, _vp]),
+    "orc_importance_sample_ggx": (None, [_sz, _vp, _vp, _vp, _vp, _vp]),
+    "orc_ggx_distribution": (None, [_sz, _vp, _vp, _vp, _vp]),
+    "orc_geometry_smith": (None, [_sz, _vp, _vp, _vp, _vp, _vp]),
+    "orc_fresnel_schlick": (None, [_sz, _vp, _vp, _vp]),
+    "orc_primary_ray": (None, [_sz, _P(abi.Camera), _vp, _vp, _vp]),
+    "orc_grid_build": (C.c_int32, [_vp, _vp, C.c_uint64, _P(_vp)]),
+    "orc_grid_describe": (None, [_vp, _P(abi.GridDesc)]),
+    "orc_grid_destroy": (None, [_vp]),
+    "orc_scene_create": (_vp, [_P(abi.Object), C.c_uint32, _P(abi.GridDesc), C.c_uint32]),
+    "orc_scene_destroy": (None, [_vp]),
+    "orc_scene_intersect": (None, [_vp, _sz, _vp, _vp, _vp, _vp]),
+    "orc_grid_intersect": (None, [_vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp]),
+    "orc_trace_sample": (C.c_int32, [_vp, _P(abi.Camera), _P(abi.Settings), C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "orc_trace_samples": (None, [_vp, _P(abi.Camera), _P(abi.Settings), _sz, _vp, _vp, _vp]),
+    "orc_render_tiles": (None, [_vp, _P(abi.Camera), _P(abi.Settings), _P(abi.TileRect), C.c_uint32, _vp, C.c_uint32]),
+    "orc_counters_reset": (None, []),
+    "orc_counters_get": (None, [_vp]),
+}
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_PATH):
+            build()
+        lib = C.CDLL(ORACLE_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class OracleScene:
+    """Owns an orc_scene built from a raymond_amd.scene.Scene."""
+
+    def __init__(self, scene):
+        self.lib = load()
+        objs, n, descs, ng, keep = scene.flatten()
+        self._keep = (objs, descs, keep)
+        self.handle = self.lib.orc_scene_create(objs, n, descs, ng)
+        assert self.handle
+
+    def close(self):
+        if self.handle:
+            self.lib.orc_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    def trace_samples(self, cam, settings, xy, samples):
+        xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+        samples = np.ascontiguousarray(samples, dtype=np.uint32)
+        out = np.zeros((xy.shape[0], 3))
+        c, s = cam.pod(), settings.pod()
+        self.lib.orc_trace_samples(self.handle, C.byref(c), C.byref(s), xy.shape[0], ptr(xy), ptr(samples), ptr(out))
+        return out
+
+    def trace_sample_path(self, cam, settings, x, y, sample):
+        rgb = np.zeros(3)
+        po = np.full(abi.RMD_MAX_BOUNCE_LIMIT + 1, -2, dtype=np.int32)
+        ps = np.zeros(abi.RMD_MAX_BOUNCE_LIMIT + 1, dtype=np.uint32)
+        c, s = cam.pod(), settings.pod()
+        n = self.lib.orc_trace_sample(self.handle, C.byref(c), C.byref(s), x, y, sample, ptr(rgb), ptr(po), ptr(ps))
+        return rgb, po[:n].copy(), ps[:n].copy()
+
+    def render_tiles(self, cam, settings, tiles, accum=None, sample_begin=0, sample_count=None, threads=0):
+        from raymond_amd.scene import tile_array
+
+        W, H = cam.backbuffer_width, cam.backbuffer_height
+        if accum is None:
+            accum = np.zeros((H, W, 3))
+        c, s = cam.pod(), settings.pod(sample_begin, sample_count)
+        self.lib.orc_render_tiles(self.handle, C.byref(c), C.byref(s), tile_array(tiles), len(tiles), ptr(accum), threads)
+        return accum
+
+    def scene_intersect(self, rays):
+        rays = f64(rays).reshape(-1, 6)
+        n = rays.shape[0]
+        obj = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n)
+        sub = np.zeros(n, dtype=np.uint32)
+        self.lib.orc_scene_intersect(self.handle, n, ptr(rays), ptr(obj), ptr(t), ptr(sub))
+        return obj, t, sub
+
+    def grid_intersect(self, g, rays):
+        rays = f64(rays).reshape(-1, 6)
+        n = rays.shape[0]
+        hit = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n)
+        tri = np.zeros(n, dtype=np.uint32)
+        self.lib.orc_grid_intersect(self.handle, g, n, ptr(rays), ptr(hit), ptr(t), ptr(tri))
+        return hit, t, tri
+
+
+def grid_build(mesh):
+    """Oracle's AccGrid::build_from_mesh -> raymond_amd.scene.AccGrid (arrays copied)."""
+    from raymond_amd.scene import AccGrid
+
+    lib = load()
+    h = C.c_void_p()
+    rc = lib.orc_grid_build(ptr(mesh.tri_pos), ptr(mesh.tri_nrm), len(mesh), C.byref(h))
+    if rc != 0:
+        return rc, None
+    d = abi.GridDesc()
+    lib.orc_grid_describe(h, C.byref(d))
+    g = AccGrid.from_desc(d)
+    lib.orc_grid_destroy(h)
+    return 0, g
+
+
+def counters():
+    out = np.zeros(8, dtype=np.uint64)
+    load().orc_counters_get(ptr(out))
+    names = ["samples", "segments", "cells", "tri_tests", "mesh_hits", "bounces", "draws", "walks"]
+    return dict(zip(names, (int(v) for v in out)))
+
+
+def counters_reset():
+    load().orc_counters_reset()

@@ -1,0 +1,438 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Levels (SURVEY.md §4 pyramid): device-function known answers -> Scene/grid intersection ->
+per-sample radiance + hit sequence -> config-1 image -> size-independent properties
+(pass splitting, tile sharding, accumulate semantics).
+
+Tolerances (binary64 everywhere; the two sides differ only in libm: glibc vs ROCm ocml for
+sin/cos/acos/pow — +,-,*,/,sqrt are correctly rounded on both and no FMA contraction is allowed):
+  * RNG, integer outputs, hit/miss flags, object/triangle ids: bit-exact;
+  * arithmetic-only device functions (intersections, ONB, normals): <= 4 ulp, in practice 0;
+  * libm-bound device functions: relative 1e-13;
+  * per-sample radiance: relative 1e-9 for >= 99.9 % of samples; the remainder must be explained by
+    a changed hit sequence (an ulp-level direction difference flipping a hit/miss or a branch);
+  * config-1 image: |d| <= 1e-9 * scale on every pixel whose samples all kept their hit sequence.
+"""
+import numpy as np
+import pytest
+
+from raymond_amd import probe, render, scenes
+from raymond_amd.scene import Settings, generate_tiles
+
+pytestmark = pytest.mark.gpu
+
+N = 4096
+
+
+def ulp_diff(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    ai = a.view(np.int64).copy()
+    bi = b.view(np.int64).copy()
+    ai[ai < 0] = np.int64(-(2**63)) - ai[ai < 0]
+    bi[bi < 0] = np.int64(-(2**63)) - bi[bi < 0]
+    d = np.abs(ai - bi)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d[both_nan] = 0
+    return d
+
+
+def rel_close(a, b, rtol):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = np.maximum(np.abs(a), np.abs(b))
+    ok = np.abs(a - b) <= rtol * np.maximum(scale, 1e-300)
+    return ok | (np.isnan(a) & np.isnan(b)) | (a == b)
+
+
+def unit(rng, n):
+    v = rng.normal(size=(n, 3))
+    return v / np.sqrt((v * v).sum(axis=1))[:, None]
+
+
+def rays_toward(rng, n, target, spread):
+    o = rng.uniform(-2, 2, size=(n, 3))
+    tgt = np.asarray(target) + rng.normal(scale=spread, size=(n, 3))
+    d = tgt - o
+    d /= np.sqrt((d * d).sum(axis=1))[:, None]
+    return np.concatenate([o, d], axis=1)
+
+
+# ------------------------------------------------------------------ level 1: RNG + device functions
+def test_philox_known_answers_on_device(gpu_ctx):
+    """Random123 kat_vectors for philox4x32-10 — the same three the oracle is pinned with."""
+    ctr = [[0, 0, 0, 0], [0xFFFFFFFF] * 4, [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]]
+    key = [[0, 0], [0xFFFFFFFF] * 2, [0xA4093822, 0x299F31D0]]
+    out = probe.philox(gpu_ctx, ctr, key)
+    expect = np.array(
+        [[0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8], [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD], [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]],
+        dtype=np.uint32,
+    )
+    assert np.array_equal(out, expect)
+
+
+def test_uniform_stream_bit_exact(gpu_ctx, oracle):
+    rng = np.random.default_rng(1)
+    pixel = rng.integers(0, 1920 * 1080, N, dtype=np.uint32)
+    sample = rng.integers(0, 4000, N, dtype=np.uint32)
+    draw = rng.integers(0, 64, N, dtype=np.uint32)
+    seed = 0x5EED0001_0BADF00D
+    dev = probe.uniform(gpu_ctx, seed, pixel, sample, draw)
+    L = oracle.load()
+    ref = np.array([L.orc_uniform(seed, int(p), int(s), int(d)) for p, s, d in zip(pixel, sample, draw)])
+    assert np.array_equal(dev, ref)
+    assert dev.min() >= 0.0 and dev.max() < 1.0
+
+
+def _oracle_hit_t(oracle, name, shape, rays):
+    L = oracle.load()
+    n = rays.shape[0]
+    hit = np.zeros(n, dtype=np.int32)
+    t = np.zeros(n)
+    getattr(L, "orc_%s_intersect" % name)(n, oracle.ptr(oracle.f64(shape)), oracle.ptr(oracle.f64(rays)), oracle.ptr(hit), oracle.ptr(t))
+    return hit, t
+
+
+@pytest.mark.parametrize("name", ["sphere", "plane", "aabb", "triangle"])
+def test_primitive_intersections(gpu_ctx, oracle, name):
+    rng = np.random.default_rng(hash(name) % 1000)
+    if name == "sphere":
+        shape = np.concatenate([rng.uniform(-1, 1, (N, 3)), rng.uniform(0.1, 1.0, (N, 1))], axis=1)
+        rays = rays_toward(rng, N, (0, 0, 0), 0.8)
+        rays[:64, :3] = shape[:64, :3]  # origin at the centre: inside => miss (Q10)
+    elif name == "plane":
+        shape = np.concatenate([rng.uniform(-1, 1, (N, 3)), unit(rng, N)], axis=1)
+        rays = rays_toward(rng, N, (0, 0, 0), 1.0)
+        rays[:64, 3:] = np.cross(shape[:64, 3:], unit(rng, 64))  # grazing: denom ~ 0 (Q11)
+    elif name == "aabb":
+        lo = rng.uniform(-1, 0, (N, 3))
+        shape = np.concatenate([lo, lo + rng.uniform(0.1, 1.5, (N, 3))], axis=1)
+        rays = rays_toward(rng, N, (0, 0, 0), 1.0)
+        rays[:64, 3] = 0.0  # axis-parallel: 1/0 = inf slabs
+        rays[64:96, 4] = -0.0
+    else:
+        c = rng.uniform(-0.5, 0.5, (N, 1, 3))
+        shape = (c + rng.normal(scale=0.4, size=(N, 3, 3))).reshape(N, 9)
+        rays = rays_toward(rng, N, (0, 0, 0), 0.5)
+        shape[:32, 3:6] = shape[:32, 0:3]  # degenerate: a ~ 0
+    dh, dt = probe.hit_t(gpu_ctx, name, shape, rays)
+    oh, ot = _oracle_hit_t(oracle, name, shape, rays)
+    assert np.array_equal(dh, oh)
+    assert 0 < oh.sum() < N
+    m = oh == 1
+    assert ulp_diff(dt[m], ot[m]).max() <= 4
+
+
+def test_normals_and_onb(gpu_ctx, oracle):
+    L = oracle.load()
+    rng = np.random.default_rng(5)
+    # sphere normal
+    sph = np.concatenate([rng.uniform(-1, 1, (N, 3)), rng.uniform(0.1, 1.0, (N, 1))], axis=1)
+    rays = rays_toward(rng, N, (0, 0, 0), 0.5)
+    t = rng.uniform(0.1, 3.0, N)
+    (dn,) = probe.call(gpu_ctx, "sphere_normal", N, [sph, rays, t], [3])
+    on = np.zeros((N, 3))
+    L.orc_sphere_normal(N, oracle.ptr(sph), oracle.ptr(rays), oracle.ptr(t), oracle.ptr(on))
+    assert ulp_diff(dn, on).max() <= 4
+    # Heron-area triangle normal (Q13), hit points inside the triangle
+    pos = rng.normal(size=(N, 9))
+    nrm = np.concatenate([unit(rng, N), unit(rng, N), unit(rng, N)], axis=1)
+    bary = rng.dirichlet((1, 1, 1), N)
+    p = bary[:, :1] * pos[:, 0:3] + bary[:, 1:2] * pos[:, 3:6] + bary[:, 2:3] * pos[:, 6:9]
+    o = p + unit(rng, N)
+    d = p - o
+    tt = np.sqrt((d * d).sum(axis=1))
+    rays = np.concatenate([o, d / tt[:, None]], axis=1)
+    (dn,) = probe.call(gpu_ctx, "triangle_normal", N, [pos, nrm, rays, tt], [3])
+    on = np.zeros((N, 3))
+    L.orc_triangle_normal(N, oracle.ptr(pos), oracle.ptr(nrm), oracle.ptr(rays), oracle.ptr(tt), oracle.ptr(on))
+    assert ulp_diff(dn, on).max() <= 4
+    # ONB incl. n.z = +-1 and n.z = 0 (sign switch)
+    n3 = unit(rng, N)
+    n3[0], n3[1], n3[2], n3[3] = (0, 0, 1), (0, 0, -1), (1, 0, 0), (0, 1, -0.0)
+    dt3, db3 = probe.call(gpu_ctx, "onb", N, [n3], [3, 3])
+    ot3, ob3 = np.zeros((N, 3)), np.zeros((N, 3))
+    L.orc_onb(N, oracle.ptr(n3), oracle.ptr(ot3), oracle.ptr(ob3))
+    assert ulp_diff(dt3, ot3).max() == 0 and ulp_diff(db3, ob3).max() == 0
+
+
+def test_samplers_and_brdf_terms(gpu_ctx, oracle):
+    L = oracle.load()
+    rng = np.random.default_rng(9)
+    r1, r2 = rng.uniform(0, 1, N), rng.uniform(0, 1, N)
+    r1[:4] = [0.0, 1.0 - 2**-53, 2**-53, 0.5]
+    r2[:4] = [0.0, 1.0 - 2**-53, 0.25, 0.75]  # r2 -> 1 blows up the GGX angle (Q3)
+    dd, dp = probe.call(gpu_ctx, "cosine_hemisphere", N, [r1, r2], [3, 1])
+    od, op = np.zeros((N, 3)), np.zeros(N)
+    L.orc_cosine_hemisphere(N, oracle.ptr(r1), oracle.ptr(r2), oracle.ptr(od), oracle.ptr(op))
+    assert np.array_equal(dp[:, 0], op)
+    assert np.abs(dd - od).max() <= 1e-15  # unit-vector components: absolute 4.5 ulp(1)
+    refl, rough = unit(rng, N), rng.uniform(0.01, 0.9, N)
+    (dg,) = probe.call(gpu_ctx, "importance_sample_ggx", N, [refl, rough, r1, r2], [3])
+    og = np.zeros((N, 3))
+    L.orc_importance_sample_ggx(N, oracle.ptr(refl), oracle.ptr(rough), oracle.ptr(r1), oracle.ptr(r2), oracle.ptr(og))
+    # sin/cos of a huge angle (r2 -> 1) is still a well-defined libm result; both sides must agree closely
+    assert np.abs(dg - og).max() <= 1e-14
+    n3, h3, v3, l3 = unit(rng, N), unit(rng, N), unit(rng, N), unit(rng, N)
+    (dD,) = probe.call(gpu_ctx, "ggx_distribution", N, [n3, h3, rough], [1])
+    oD = np.zeros(N)
+    L.orc_ggx_distribution(N, oracle.ptr(n3), oracle.ptr(h3), oracle.ptr(rough), oracle.ptr(oD))
+    assert ulp_diff(dD[:, 0], oD).max() <= 2
+    (dG,) = probe.call(gpu_ctx, "geometry_smith", N, [n3, v3, l3, rough], [1])
+    oG = np.zeros(N)
+    L.orc_geometry_smith(N, oracle.ptr(n3), oracle.ptr(v3), oracle.ptr(l3), oracle.ptr(rough), oracle.ptr(oG))
+    assert ulp_diff(dG[:, 0], oG).max() <= 2
+    cos_t, f0 = rng.uniform(-1, 1, N), rng.uniform(0, 1, (N, 3))
+    (dF,) = probe.call(gpu_ctx, "fresnel_schlick", N, [cos_t, f0], [3])
+    oF = np.zeros((N, 3))
+    L.orc_fresnel_schlick(N, oracle.ptr(cos_t), oracle.ptr(f0), oracle.ptr(oF))
+    assert rel_close(dF, oF, 1e-13).all()
+
+
+def test_primary_ray(gpu_ctx, oracle):
+    import ctypes as C
+
+    L = oracle.load()
+    rng = np.random.default_rng(11)
+    cam = scenes.camera(1920, 1080)
+    xy = np.stack([rng.integers(0, 1920, N), rng.integers(0, 1080, N)], axis=1).astype(np.uint32)
+    u = rng.uniform(0, 1, (N, 2))
+    dev = probe.primary_ray(gpu_ctx, cam, xy, u)
+    ref = np.zeros((N, 6))
+    c = cam.pod()
+    L.orc_primary_ray(N, C.byref(c), oracle.ptr(xy), oracle.ptr(u), oracle.ptr(ref))
+    assert ulp_diff(dev, ref).max() == 0  # tan() is evaluated by the host libm on both sides
+
+
+# ------------------------------------------------------------------ level 2: scene + grid intersection
+@pytest.fixture(scope="module")
+def small_mesh_scene(product_lib):
+    return scenes.gold_dragon_standin(n=24)  # 6,912 triangles
+
+
+def test_scene_intersect_spheres(gpu_ctx, oracle):
+    sc = scenes.reflective_spheres()
+    ds, osc = render.DeviceScene(gpu_ctx, sc), oracle.OracleScene(sc)
+    rng = np.random.default_rng(13)
+    rays = np.concatenate([rays_toward(rng, N, (-1.0, -0.5, 3.5), 0.6), rays_toward(rng, N, (0.74, -0.25, 3.5), 0.9), rays_toward(rng, N, (0, 0, 2), 3.0)])
+    dobj, dt, dsub = probe.scene_intersect(gpu_ctx, ds, rays)
+    oobj, ot, osub = osc.scene_intersect(rays)
+    assert np.array_equal(dobj, oobj) and np.array_equal(dsub, osub)
+    assert len(set(oobj.tolist())) >= 7
+    m = oobj >= 0
+    assert ulp_diff(dt[m], ot[m]).max() <= 4
+    ds.close()
+
+
+def test_grid_walk(gpu_ctx, oracle, small_mesh_scene):
+    """AccGrid::intersects incl. origins inside the box, on the max side (Q6) and axis-parallel rays (Q8)."""
+    sc = small_mesh_scene
+    ds, osc = render.DeviceScene(gpu_ctx, sc), oracle.OracleScene(sc)
+    g = sc.objects[1].geometry.grid
+    centre = (g.bbox_min + g.bbox_max) / 2
+    rng = np.random.default_rng(17)
+    rays = rays_toward(rng, 3 * N, centre, 0.06)
+    inside = np.concatenate([rng.uniform(g.bbox_min, g.bbox_max, (N, 3)), unit(rng, N)], axis=1)
+    beyond = np.concatenate([g.bbox_max + rng.uniform(0.001, 0.2, (N, 3)), -unit(rng, N) * np.sign(rng.uniform(-0.2, 1, (N, 3)))], axis=1)
+    beyond[:, 3:] /= np.sqrt((beyond[:, 3:] ** 2).sum(axis=1))[:, None]
+    axis = np.concatenate([centre + rng.uniform(-0.05, 0.05, (64, 3)) - np.array([0, 0, 1.0]), np.tile([0.0, -0.0, 1.0], (64, 1))], axis=1)
+    rays = np.concatenate([rays, inside, beyond, axis])
+    dh, dt, dtri = probe.grid_intersect(gpu_ctx, ds, 0, rays)
+    oh, ot, otri = osc.grid_intersect(0, rays)
+    assert np.array_equal(dh, oh)
+    assert 0.1 < oh.mean() < 0.95
+    m = oh == 1
+    assert np.array_equal(dtri[m], otri[m])
+    assert ulp_diff(dt[m], ot[m]).max() <= 4
+    dobj, dt2, dsub = probe.scene_intersect(gpu_ctx, ds, rays)
+    oobj, ot2, osub = osc.scene_intersect(rays)
+    assert np.array_equal(dobj, oobj) and np.array_equal(dsub, osub)
+    ds.close()
+
+
+# ------------------------------------------------------------------ level 3: per-sample radiance + hit sequence
+def _per_sample(gpu_ctx, oracle, scene, settings, n, seed):
+    cam = settings.camera_settings
+    rng = np.random.default_rng(seed)
+    xy = np.stack([rng.integers(0, cam.backbuffer_width, n), rng.integers(0, cam.backbuffer_height, n)], axis=1).astype(np.uint32)
+    smp = rng.integers(0, 4000, n).astype(np.uint32)
+    ds, osc = render.DeviceScene(gpu_ctx, scene), oracle.OracleScene(scene)
+    drgb, dpo, dps = probe.trace_samples(gpu_ctx, ds, cam, settings, xy, smp, paths=True)
+    orgb = np.zeros((n, 3))
+    opo = np.full((n, probe.PATH_STRIDE), -2, dtype=np.int32)
+    ops = np.zeros((n, probe.PATH_STRIDE), dtype=np.uint32)
+    for i in range(n):
+        rgb, po, ps = osc.trace_sample_path(cam, settings, int(xy[i, 0]), int(xy[i, 1]), int(smp[i]))
+        orgb[i] = rgb
+        opo[i, : len(po)] = po
+        ops[i, : len(ps)] = ps
+    ds.close()
+    same_path = (dpo == opo).all(axis=1) & (dps == ops).all(axis=1)
+    close = rel_close(drgb, orgb, 1e-9).all(axis=1)
+    return same_path, close, drgb, orgb
+
+
+@pytest.mark.parametrize("config", ["C1", "C2"])
+def test_per_sample_spheres(gpu_ctx, oracle, config):
+    n = 20000
+    st = scenes.config_settings(config)
+    same_path, close, drgb, orgb = _per_sample(gpu_ctx, oracle, scenes.reflective_spheres(), st, n, 23)
+    assert close[same_path].all(), "a sample with the oracle's exact hit sequence differs beyond 1e-9"
+    assert same_path.mean() >= 0.999, "more than 0.1 %% of samples changed their hit sequence: %g" % (1 - same_path.mean())
+    assert close.mean() >= 0.999
+    assert (orgb > 0).any(axis=1).mean() > 0.05  # the comparison is not vacuous
+
+
+def test_per_sample_mesh(gpu_ctx, oracle, small_mesh_scene):
+    st = Settings(scenes.camera(480, 270), sample_count=1, bounce_limit=5, seed=scenes.SEED)
+    same_path, close, drgb, orgb = _per_sample(gpu_ctx, oracle, small_mesh_scene, st, 20000, 29)
+    assert close[same_path].all()
+    assert same_path.mean() >= 0.999 and close.mean() >= 0.999
+
+
+def test_per_sample_dof_and_deep_bounces(gpu_ctx, oracle, small_mesh_scene):
+    """Config-5 style thin lens (rejection-sampled aperture, variable draw count, Q12) and bounce_limit 8 (config 4)."""
+    st = Settings(scenes.camera(480, 270, aperture_radius=0.5), sample_count=1, bounce_limit=8, seed=scenes.SEED + 5)
+    same_path, close, drgb, orgb = _per_sample(gpu_ctx, oracle, small_mesh_scene, st, 12000, 31)
+    assert close[same_path].all()
+    assert same_path.mean() >= 0.999 and close.mean() >= 0.999
+
+
+def test_bounce_limit_edge_cases(gpu_ctx, oracle):
+    sc = scenes.reflective_spheres()
+    for limit in (0, 1, 16):
+        st = Settings(scenes.camera(64, 64), sample_count=1, bounce_limit=limit, seed=3)
+        same_path, close, drgb, orgb = _per_sample(gpu_ctx, oracle, sc, st, 2000, 37 + limit)
+        assert close[same_path].all() and same_path.mean() >= 0.998
+        if limit == 0:
+            assert (drgb == 0).all()  # depth 1 > bounce_limit: trace() returns 0 before intersecting (:235-237)
+
+
+# ------------------------------------------------------------------ level 4: config-1 image
+def test_config1_image(gpu_ctx, oracle):
+    """ReflectiveSpheres 256x256, 16 spp, 3 bounces (BASELINE.json configs[0]) — whole image vs oracle."""
+    sc, st = scenes.reflective_spheres(), scenes.config_settings("C1")
+    cam = st.camera_settings
+    tiles = generate_tiles(256, 256, st.tile_size)
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, 256, 256)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+    dev = fb.download()
+    ref = oracle.OracleScene(sc).render_tiles(cam, st, tiles)
+    ok = rel_close(dev, ref, 1e-9).all(axis=2)
+    assert ok.mean() >= 0.995, "pixels off: %d" % (~ok).sum()
+    # pixels that differ must differ by at most a few whole samples' worth of radiance (a flipped sample), not garbage
+    assert np.abs(dev - ref)[~ok].max(initial=0.0) <= 16 * 1.5 * 4
+    assert abs(dev.mean() - ref.mean()) <= 1e-3 * ref.mean()
+    # tone-mapped 8-bit output (cli_old/src/main.rs:161-181) is identical wherever the radiance agrees
+    rgb8 = render.resolve_tonemap(gpu_ctx, fb, st.sample_count)
+    ref8 = np.trunc(255.0 * np.power(1.0 - np.exp(-(ref / 16.0)), 1.0 / 2.2)).astype(np.uint8)
+    assert (rgb8[ok] == ref8[ok]).mean() >= 0.999
+    fb.close()
+    ds.close()
+
+
+# ------------------------------------------------------------------ level 5: size-independent properties
+def test_pass_splitting_and_accumulate_are_bit_exact(gpu_ctx):
+    """One 12-sample launch == 5+7 samples in two launches (sample_begin) == += semantics on a pre-filled buffer."""
+    sc = scenes.reflective_spheres()
+    st = Settings(scenes.camera(200, 120), sample_count=12, bounce_limit=5, seed=77)
+    cam = st.camera_settings
+    tiles = generate_tiles(200, 120, (32, 32))  # ragged: 200 = 6*32 + 8, 120 = 3*32 + 24
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fa, fb = render.Framebuffer(gpu_ctx, 200, 120), render.Framebuffer(gpu_ctx, 200, 120)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fa, 0, 12)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, 0, 5)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, 5, 7)
+    a, b = fa.download(), fb.download()
+    assert a.tobytes() == b.tobytes()
+    assert (a > 0).mean() > 0.3
+    # zero-sample pass leaves the buffer untouched
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, 12, 0)
+    assert fb.download().tobytes() == a.tobytes()
+    # accumulate on top of existing content
+    base = np.random.default_rng(3).uniform(0, 1, a.shape)
+    fb.upload(base)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles[:5], fb, 0, 1)
+    c = fb.download()
+    untouched = np.ones((120, 200), dtype=bool)
+    for (l, t, w, h) in tiles[:5]:
+        untouched[t : t + h, l : l + w] = False
+    assert (c[untouched] == base[untouched]).all()
+    assert (c[~untouched] != base[~untouched]).any()
+    fa.close(), fb.close(), ds.close()
+
+
+def test_tile_shards_sum_to_the_full_image(gpu_ctx, small_mesh_scene):
+    """8 disjoint round-robin tile shards rendered into zeroed buffers and summed == one full render, bit for bit
+    (the multi-GPU reduce in miniature)."""
+    st = Settings(scenes.camera(320, 180), sample_count=4, bounce_limit=5, seed=99)
+    cam = st.camera_settings
+    tiles = generate_tiles(320, 180, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, small_mesh_scene)
+    full = render.Framebuffer(gpu_ctx, 320, 180)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, full)
+    ref = full.download()
+    total = np.zeros_like(ref)
+    part = render.Framebuffer(gpu_ctx, 320, 180)
+    for r in range(8):
+        part.zero()
+        render.render_tiles(gpu_ctx, ds, cam, st, tiles[r::8], part)
+        total += part.download()
+    assert total.tobytes() == ref.tobytes()
+    full.close(), part.close(), ds.close()
+
+
+def test_host_buffer_entry_point_matches_device_path(gpu_ctx):
+    import ctypes as C
+
+    sc = scenes.reflective_spheres()
+    st = Settings(scenes.camera(64, 48), sample_count=3, bounce_limit=4, seed=5)
+    cam = st.camera_settings
+    tiles = generate_tiles(64, 48, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, 64, 48)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+    host = np.zeros((48, 64, 3))
+    from raymond_amd.scene import tile_array
+
+    c, s = cam.pod(), st.pod()
+    gpu_ctx.check(gpu_ctx.L.rmd_render_tiles_host(gpu_ctx.handle, ds.handle, C.byref(c), C.byref(s), tile_array(tiles), len(tiles), host.ctypes.data_as(C.c_void_p)))
+    assert host.tobytes() == fb.download().tobytes()
+    fb.close(), ds.close()
+
+
+def test_reference_shaped_api_end_to_end(gpu_ctx):
+    """render_tiled(scene, settings).await_() — the reference's call sequence (cli_old/src/main.rs:152-153)."""
+    sc = scenes.reflective_spheres()
+    st = Settings(scenes.camera(96, 64), sample_count=8, tile_size=(32, 32), bounce_limit=5, seed=11)
+    img = render.render_tiled(sc, st).await_()
+    assert img.shape == (64, 96, 3) and np.isfinite(img).all()
+    # progressive passes (samples_per_iteration, src/trace.rs:217-219) converge on the same sums
+    st2 = Settings(scenes.camera(96, 64), sample_count=8, tile_size=(32, 32), bounce_limit=5, seed=11, samples_per_iteration=3)
+    h = render.render_tiled(sc, st2)
+    progressed = []
+    h.set_callback(lambda tile: progressed.append(tile.sample_count))
+    h.async_await()
+    assert progressed and set(progressed) == {3, 6}
+    assert h.await_().tobytes() == img.tobytes()
+    # ceiling light: emission 1.5 seen directly by the top rows
+    assert abs(img[0, 48].mean() - 1.5) < 1e-12
+
+
+def test_error_paths(gpu_ctx):
+    import ctypes as C
+
+    from raymond_amd import abi, lib
+
+    sc = scenes.reflective_spheres()
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, 32, 32)
+    st = Settings(scenes.camera(32, 32), sample_count=1, bounce_limit=17)
+    with pytest.raises(lib.RaymondError) as e:
+        render.render_tiles(gpu_ctx, ds, st.camera_settings, st, [(0, 0, 32, 32)], fb)
+    assert e.value.status == abi.RMD_ERR_UNSUPPORTED
+    st = Settings(scenes.camera(32, 32), sample_count=1, bounce_limit=2)
+    with pytest.raises(lib.RaymondError) as e:
+        render.render_tiles(gpu_ctx, ds, st.camera_settings, st, [(16, 16, 32, 32)], fb)  # outside the backbuffer
+    assert e.value.status == abi.RMD_ERR_INVALID_ARGUMENT
+    assert b"outside" in gpu_ctx.L.rmd_last_error(gpu_ctx.handle)
+    fb.close(), ds.close()

@@ -1,0 +1,25 @@
+"""Scratch timing of the render kernel (not the bench): python tools/quick_time.py [C2|C3] [spp]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raymond_amd import render, scenes
+from raymond_amd.scene import generate_tiles
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C2"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+st = scenes.config_settings(name, spp=spp)
+cam = st.camera_settings
+sc = getattr(scenes, scenes.CONFIGS[name][0])()
+tiles = generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size)
+with render.Context(0) as ctx:
+    ds = render.DeviceScene(ctx, sc)
+    fb = render.Framebuffer(ctx, cam.backbuffer_width, cam.backbuffer_height)
+    for it in range(3):
+        fb.zero()
+        t = time.time()
+        render.render_tiles(ctx, ds, cam, st, tiles, fb)
+        dt = time.time() - t
+        ms = ctx.last_kernel_ms()
+        n = cam.backbuffer_width * cam.backbuffer_height * spp
+        print("%s spp=%d wall %.3fs kernel %.1f ms -> %.1f Msamples/s" % (name, spp, dt, ms, n / ms / 1e3), flush=True)
+    img = fb.download()
+    print("mean radiance", img.mean() / spp)
