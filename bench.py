@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Msamples/s of the ReflectiveSpheres scene, 1920x1080 @ 500 spp, 5 bounces (config C2).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over the workload: every pixel of the 1920x1080 frame receives all 500
+samples (rmd_render_tiles over this rank's share of the 32x32 host tiles, sample_begin 0, sample_count 500) and, for
+N > 1, the accumulated f64 framebuffer is summed onto rank 0 with one RCCL reduce.  The frame is a fixed amount of
+work split over the ranks (tile i -> rank i mod N), so scaling is "strong".  Scene, camera and tile list are resident
+in HBM before the timed region; the timed region is bracketed by barrier + synchronize and the maximum over ranks
+is reported.
+
+The JSON line also carries
+  roofline      HBM roofline of the traversal (same kernel, GoldDragon-standin mesh, config C3 at reduced spp): the
+                spheres workload touches ~0.05 B/sample and is FP64-VALU bound, so its HBM fraction is reported
+                separately as roofline_c2 and is not the figure to optimise;
+  cpu_baseline  the CPU oracle (reference-equivalent C++ restatement, kind "port") timed on this box's host cores
+                on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (default: the config's)")
+    ap.add_argument("--roofline-spp", type=int, default=50, help="spp of the C3 roofline leg")
+    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-leg", action="store_true")
+    return ap.parse_args()
+
+
+def load_counters():
+    """Per-sample work counts of the oracle (cells visited, triangle tests, mesh hits), committed fixtures."""
+    path = os.path.join(ROOT, "tests", "golden", "work_counters.json")
+    with open(path) as f:
+        return json.load(f)
+
+
+def algorithmic_bytes_per_sample(name, spp, counters):
+    """8*C + 76*T + 72*H + 24/spp bytes per sample (C cells, T triangle tests, H shaded mesh hits)."""
+    c = counters.get(name)
+    if c is None:
+        return None
+    n = float(c["samples"])
+    return 8.0 * c["cells"] / n + 76.0 * c["tri_tests"] / n + 72.0 * c["mesh_hits"] / n + 24.0 / spp
+
+
+def load_traffic(name):
+    """Measured HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(name)
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE is unset)" % args.gpus)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from raymond_amd import render, scenes
+    from raymond_amd.scene import generate_tiles, tile_array
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    def setup(name, spp):
+        st = scenes.config_settings(name, spp=spp)
+        cam = st.camera_settings
+        sc = getattr(scenes, scenes.CONFIGS[name][0])()
+        tiles = generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size)
+        share = tiles[rank::world]  # tile i -> rank i mod N
+        return st, cam, sc, tiles, share
+
+    # everything launches on torch's current stream so that zeroing, the render kernel and the reduce are ordered
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = render.Context(local_rank, stream=stream)
+
+    def run_workload(name, spp, steps, warmup, reduce):
+        st, cam, sc, tiles, share = setup(name, spp)
+        W, H = cam.backbuffer_width, cam.backbuffer_height
+        ds = render.DeviceScene(ctx, sc)
+        fb_t = torch.zeros(W * H * 3, dtype=torch.float64, device=dev)
+        fb = render.Framebuffer(ctx, W, H, device_ptr=fb_t.data_ptr())
+        arr = (tile_array(share), len(share))
+        kernel_ms = []
+
+        def step():
+            fb_t.zero_()
+            render.render_tiles(ctx, ds, cam, st, arr, fb, 0, st.sample_count, sync=False)
+            if reduce and dist is not None:
+                dist.reduce(fb_t, dst=0, op=dist.ReduceOp.SUM)
+
+        for _ in range(warmup):
+            step()
+            torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            # HIP events recorded by the library around the kernel, on the stream it was launched on
+            kernel_ms.append(ctx.last_kernel_ms())
+        torch.cuda.synchronize(dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        checksum = float(fb_t.sum().item()) if rank == 0 else 0.0
+        ds.close()
+        samples_per_step = W * H * st.sample_count
+        my_samples = sum(w * h for (_, _, w, h) in share) * st.sample_count
+        return dict(st=st, W=W, H=H, elapsed=elapsed, kernel_ms=kernel_ms, samples_per_step=samples_per_step,
+                    my_samples=my_samples, checksum=checksum, n_tiles=len(tiles))
+
+    name = args.workload
+    spp = args.spp if args.spp is not None else scenes.CONFIGS[name][3]
+    main_run = run_workload(name, spp, args.steps, args.warmup, reduce=True)
+    ms_per_step = main_run["elapsed"] / args.steps * 1e3
+    value = main_run["samples_per_step"] * args.steps / main_run["elapsed"] / 1e6
+
+    out = {
+        "metric": "Msamples/s (whole node) + achieved HBM GB/s, 1920x1080 @ 500spp 5-bounce",
+        "value": round(value, 3),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %s, %dx%d, %d spp, %d bounces, 32x32 host tiles round-robin over %d GPU(s)%s"
+            % (name, scenes.CONFIGS[name][0], main_run["W"], main_run["H"], spp, main_run["st"].bounce_limit, world,
+               ", RCCL reduce(sum) of the f64 framebuffer to rank 0" if world > 1 else ""),
+            "rng": "philox4x32-10 keyed (seed; pixel, sample, draw)",
+            "seed": scenes.SEED,
+        },
+    }
+
+    if rank == 0:
+        counters = load_counters()
+        avg_ms = sum(main_run["kernel_ms"]) / len(main_run["kernel_ms"])
+        bps = algorithmic_bytes_per_sample(name, spp, counters)
+        if bps is None:
+            bps = 24.0 / spp
+        ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
+        out["kernel"] = {"name": "rmd::render_kernel<false>", "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]),
+                         "checksum": main_run["checksum"]}
+        out["roofline_%s" % name.lower()] = {
+            "bound": "hbm", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": load_traffic(name), "bytes_per_sample": bps,
+            "note": "FP64-VALU bound workload (8-object scene lives in LDS/SGPRs); HBM traffic is the framebuffer only" if name == "C2" else "",
+        }
+
+    # roofline leg: the traversal on the ~100k-triangle mesh (config C3, reduced spp; throughput is spp-independent)
+    if not args.no_roofline_leg and world == 1:
+        rspp = args.roofline_spp
+        rr = run_workload("C3", rspp, 3, 1, reduce=False)
+        counters = load_counters()
+        bps = algorithmic_bytes_per_sample("C3", rspp, counters)
+        avg_ms = sum(rr["kernel_ms"]) / len(rr["kernel_ms"])
+        ach = bps * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": load_traffic("C3"),
+            "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces" % rspp,
+            "kernel": "rmd::render_kernel<false>", "avg_ms": round(avg_ms, 3),
+            "bytes_per_sample": round(bps, 2), "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
+        }
+    elif rank == 0:
+        out["roofline"] = out.get("roofline_%s" % name.lower())
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+
+        st, cam, sc, tiles, _ = setup(name, args.cpu_spp)
+        osc = oracle_lib.OracleScene(sc)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        osc.render_tiles(cam, st, tiles, threads=cores)
+        dt = time.perf_counter() - t0
+        n = cam.backbuffer_width * cam.backbuffer_height * args.cpu_spp
+        out["cpu_baseline"] = {
+            "value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%s at %dx%d, %d spp (%.1f M samples, %.1f s): reference-equivalent C++ restatement, worker pool of %d threads, 32x32 tiles, -O2"
+            % (name, cam.backbuffer_width, cam.backbuffer_height, args.cpu_spp, n / 1e6, dt, cores),
+        }
+        out["speedup_vs_cpu_baseline"] = round(value / (n / dt / 1e6), 1)
+
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

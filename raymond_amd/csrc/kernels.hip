@@ -99,7 +99,8 @@ __global__ __launch_bounds__(64) void render_kernel(RenderParams P, const DevObj
 			depth = 1;
 			specmask = 0;
 			fresh = false;
-			if (!ok) terminal = true; // reference panics here; the sample contributes zero
+			if (!ok) terminal = true;                  // reference panics here; the sample contributes zero
+			if (P.bounce_limit == 0u) terminal = true; // trace(…, 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237)
 		}
 		if (!terminal) {
 			// src/trace.rs:239

@@ -34,12 +34,17 @@ def reflective_spheres():
     return scene
 
 
-def lumpy_sphere_mesh(n=91, extent=(0.21, 0.15, 0.09)):
+def lumpy_sphere_mesh(n=91, extent=(2.3, 1.7, 1.0), centre=(0.0, 0.15, 0.0)):
     """Closed, smooth-shaded procedural mesh with 12*n*n triangles (n=91 -> 99,372).
 
     A cube-sphere (lattice points of the cube surface pushed onto the unit sphere) whose radius is
-    modulated by Chebyshev-polynomial lobes, then scaled into `extent` (the Stanford dragon's
-    rough proportions).  Vertex normals are area-weighted face-normal sums.
+    modulated by Chebyshev-polynomial lobes, then scaled into `extent` and moved to `centre`.
+    The defaults reproduce the footprint of the dragon in the reference's examples/GoldDragon.png
+    (592x340, f = 170/tan(27.5 deg) = 326.6 px): it spans ~260 x 195 px at z ~ 2.9, i.e. ~2.3 x 1.7
+    world units, stands on the floor plane y = -1 after the (0, -0.3, 2.9) bake of cli_old/src/main.rs:61,
+    and keeps the Stanford dragon's 0.21 : 0.15 : 0.09 proportions (depth 1.0).  size.z <= size.y, as the
+    reference's `res.z` index quirk (Q5) requires of any mesh it can build a grid for.
+    Vertex normals are area-weighted face-normal sums.
     """
     idx = {}
     verts = []
@@ -78,7 +83,7 @@ def lumpy_sphere_mesh(n=91, extent=(0.21, 0.15, 0.09)):
     radius = 1.0 + 0.22 * t3(x) * t3(y) + 0.15 * t2(z) * t3(y) + 0.10 * t3(z) * t2(x)
     p = d * radius[:, None]
     half = np.max(np.abs(p), axis=0)
-    p = p * (np.asarray(extent, dtype=np.float64) * 0.5 / half)[None, :]
+    p = p * (np.asarray(extent, dtype=np.float64) * 0.5 / half)[None, :] + np.asarray(centre, dtype=np.float64)[None, :]
     p0, p1, p2 = p[faces[:, 0]], p[faces[:, 1]], p[faces[:, 2]]
     e1, e2 = p1 - p0, p2 - p0
     fn = np.stack(

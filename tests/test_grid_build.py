@@ -59,7 +59,7 @@ def test_full_size_standin_grid_matches_oracle(oracle, product_lib):
 def test_q5_index_panic_is_an_error_not_a_crash(oracle, product_lib):
     """A mesh deeper (z) than tall (y) makes `x + res.x*(y + z*res.z)` exceed the cell array: the
     reference panics at acc_grid.rs:61; both builders must report it as status 5."""
-    mesh = scenes.lumpy_sphere_mesh(6, extent=(0.2, 0.05, 0.3))
+    mesh = scenes.lumpy_sphere_mesh(6, extent=(2.0, 0.5, 3.0))
     rc, _ = oracle.grid_build(mesh)
     assert rc == abi.RMD_ERR_GRID_INDEX
     with pytest.raises(lib.RaymondError) as e:
