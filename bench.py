@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (default: the config's)")
     ap.add_argument("--roofline-spp", type=int, default=50, help="spp of the C3 roofline leg")
-    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = calibrate to ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
     return ap.parse_args()
@@ -91,7 +91,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from raymond_amd import render, scenes
+    from raymond_amd import render, scenes, shard
     from raymond_amd.scene import generate_tiles, tile_array
 
     def barrier():
@@ -103,7 +103,7 @@ def main():
         cam = st.camera_settings
         sc = getattr(scenes, scenes.CONFIGS[name][0])()
         tiles = generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size)
-        share = tiles[rank::world]  # tile i -> rank i mod N
+        share = shard.shard_tiles(tiles, rank, world)  # tile i -> rank i mod N
         return st, cam, sc, tiles, share
 
     # everything launches on torch's current stream so that zeroing, the render kernel and the reduce are ordered
@@ -123,7 +123,7 @@ def main():
             fb_t.zero_()
             render.render_tiles(ctx, ds, cam, st, arr, fb, 0, st.sample_count, sync=False)
             if reduce and dist is not None:
-                dist.reduce(fb_t, dst=0, op=dist.ReduceOp.SUM)
+                shard.reduce_framebuffer(dist, fb_t, root=0)
 
         for _ in range(warmup):
             step()
@@ -145,7 +145,7 @@ def main():
         checksum = float(fb_t.sum().item()) if rank == 0 else 0.0
         ds.close()
         samples_per_step = W * H * st.sample_count
-        my_samples = sum(w * h for (_, _, w, h) in share) * st.sample_count
+        my_samples = shard.shard_samples(share) * st.sample_count
         return dict(st=st, W=W, H=H, elapsed=elapsed, kernel_ms=kernel_ms, samples_per_step=samples_per_step,
                     my_samples=my_samples, checksum=checksum, n_tiles=len(tiles))
 
@@ -214,17 +214,23 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
 
-        st, cam, sc, tiles, _ = setup(name, args.cpu_spp)
-        osc = oracle_lib.OracleScene(sc)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        # calibrate on 1 spp, then size the sample for ~15 s of CPU work (the rate is spp-independent)
+        st, cam, sc, tiles, _ = setup(name, 1)
+        osc = oracle_lib.OracleScene(sc)
+        t0 = time.perf_counter()
+        osc.render_tiles(cam, st, tiles, threads=cores)
+        t1 = time.perf_counter() - t0
+        cpu_spp = args.cpu_spp if args.cpu_spp > 0 else max(2, min(256, int(15.0 / max(t1, 1e-3))))
+        st = scenes.config_settings(name, spp=cpu_spp)
         t0 = time.perf_counter()
         osc.render_tiles(cam, st, tiles, threads=cores)
         dt = time.perf_counter() - t0
-        n = cam.backbuffer_width * cam.backbuffer_height * args.cpu_spp
+        n = cam.backbuffer_width * cam.backbuffer_height * cpu_spp
         out["cpu_baseline"] = {
             "value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%s at %dx%d, %d spp (%.1f M samples, %.1f s): reference-equivalent C++ restatement, worker pool of %d threads, 32x32 tiles, -O2"
-            % (name, cam.backbuffer_width, cam.backbuffer_height, args.cpu_spp, n / 1e6, dt, cores),
+            "sample": "%s at %dx%d, %d spp (%.1f M samples, %.1f s): reference-equivalent C++ restatement (oracle/), worker pool of %d threads as num_cpus::get(), 32x32 tiles, g++ -O2"
+            % (name, cam.backbuffer_width, cam.backbuffer_height, cpu_spp, n / 1e6, dt, cores),
         }
         out["speedup_vs_cpu_baseline"] = round(value / (n / dt / 1e6), 1)
 

@@ -1,0 +1,111 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol the headers declare, the ctypes
+mirror has the C layout, and a call that needs a device fails loudly with a status and a message."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+from raymond_amd import abi, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("raymond_hip.h", "raymond_hip_probe.h")]
+
+
+def declared_functions():
+    names = set()
+    for h in HEADERS:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(rmd_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported(product_lib):
+    names = declared_functions()
+    assert len(names) >= 40
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (rmd_[a-z0-9_]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+    assert set(lib.SIGNATURES) <= exported
+    # the boundary is plain C: no C++-mangled rmd entry points, no torch types anywhere near it
+    assert not re.search(r" T _Z\w*rmd_render", out)
+    assert product_lib.rmd_abi_version() == abi.RMD_ABI_VERSION
+
+
+def test_library_does_not_link_the_oracle_or_torch():
+    out = subprocess.run(["ldd", lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "liboracle" not in out and "torch" not in out and "libamdhip64" in out
+    needed = subprocess.run(["readelf", "-d", lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "rccl" not in needed  # resolved lazily with dlopen, only by rmd_comm_*
+
+
+def test_struct_layout_matches_the_c_header():
+    src = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "raymond_hip.h"
+#define S(T) printf(#T " %zu\n", sizeof(T))
+#define O(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
+int main(void) {
+  S(rmd_material); O(rmd_material, color); O(rmd_material, roughness); O(rmd_material, emission_aux);
+  S(rmd_object); O(rmd_object, grid_index); O(rmd_object, origin); O(rmd_object, normal); O(rmd_object, radius); O(rmd_object, material);
+  S(rmd_grid_desc); O(rmd_grid_desc, bbox_max); O(rmd_grid_desc, resolution); O(rmd_grid_desc, cell_size); O(rmd_grid_desc, cells);
+  O(rmd_grid_desc, n_cells); O(rmd_grid_desc, mapping_table); O(rmd_grid_desc, n_mapping); O(rmd_grid_desc, tri_pos); O(rmd_grid_desc, tri_nrm); O(rmd_grid_desc, n_tris);
+  S(rmd_camera); O(rmd_camera, fov_vert); O(rmd_camera, position); O(rmd_camera, focal_length); O(rmd_camera, aperture_radius);
+  S(rmd_settings); O(rmd_settings, sample_begin); O(rmd_settings, sample_count); O(rmd_settings, seed);
+  S(rmd_tile_rect); O(rmd_tile_rect, height);
+  return 0; }
+"""
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "layout.c"), os.path.join(d, "layout")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    c_layout = dict((l.split()[0], int(l.split()[1])) for l in lines if l.strip())
+    py = {"rmd_material": abi.Material, "rmd_object": abi.Object, "rmd_grid_desc": abi.GridDesc, "rmd_camera": abi.Camera,
+          "rmd_settings": abi.Settings, "rmd_tile_rect": abi.TileRect}
+    for key, val in c_layout.items():
+        if "." in key:
+            t, f = key.split(".")
+            assert getattr(py[t], f).offset == val, key
+        else:
+            assert C.sizeof(py[key]) == val, key
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK), reason="a GPU is present")
+def test_no_device_is_a_loud_error_not_a_fallback(product_lib):
+    h = C.c_void_p()
+    status = product_lib.rmd_context_create(0, C.byref(h))
+    assert status == abi.RMD_ERR_NO_DEVICE and not h
+    assert b"no HIP device" in product_lib.rmd_last_error(None)
+    from raymond_amd import render
+
+    with pytest.raises(lib.RaymondError):
+        render.Context(0)
+
+
+def test_null_arguments_are_rejected(product_lib):
+    assert product_lib.rmd_context_create(0, None) == abi.RMD_ERR_INVALID_ARGUMENT
+    assert product_lib.rmd_render_tiles(None, None, None, None, None, 0, None) == abi.RMD_ERR_INVALID_ARGUMENT
+    assert product_lib.rmd_comm_unique_id(None) == abi.RMD_ERR_INVALID_ARGUMENT
+    product_lib.rmd_context_destroy(None)  # no-ops, like free(NULL)
+    product_lib.rmd_scene_destroy(None)
+    product_lib.rmd_grid_build_destroy(None)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under raymond_amd/ (or bench.py outside its cpu_baseline leg) may
+    import, link or name it."""
+    pkg = os.path.join(ROOT, "raymond_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="ignore").read()
+                for needle in ("oracle_lib", "liboracle", "orc_", "oracle.h", "import oracle"):
+                    assert needle not in text, "%s mentions %s" % (os.path.join(base, f), needle)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("import oracle_lib") == 1 and bench.index("import oracle_lib") > bench.index("not args.no_cpu_baseline")

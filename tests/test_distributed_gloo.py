@@ -1,0 +1,87 @@
+"""N > 1 host logic on CPU: two gloo ranks shard the tiles (raymond_amd.shard), render their share into zeroed
+full-size framebuffers and reduce(sum) to rank 0 — which must equal the single-process image bit for bit
+(SURVEY.md §8e).  The renderer here is the CPU oracle (this test checks the sharding/reduce logic, which is what
+bench.py --gpus N runs around rmd_render_tiles; the GPU equivalent is test_tile_shards_sum_to_the_full_image)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import oracle_lib
+    from raymond_amd import scenes, shard
+    from raymond_amd.scene import Settings, generate_tiles
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st = Settings(scenes.camera(160, 96), sample_count=3, tile_size=(32, 32), bounce_limit=4, seed=21)
+        cam = st.camera_settings
+        tiles = generate_tiles(160, 96, st.tile_size)
+        mine = shard.shard_tiles(tiles, rank, world)
+        osc = oracle_lib.OracleScene(scenes.reflective_spheres())
+        fb = torch.from_numpy(osc.render_tiles(cam, st, mine, threads=2))
+        covered = torch.tensor([float(shard.shard_samples(mine))], dtype=torch.float64)
+        dist.barrier()
+        shard.reduce_framebuffer(dist, fb, root=0)
+        dist.all_reduce(covered)
+        assert int(covered.item()) == 160 * 96  # the shards partition the frame
+        if rank == 0:
+            np.save(out_path, fb.numpy())
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_render_plus_reduce_equals_single_process(oracle, tmp_path, world):
+    import torch.multiprocessing as mp
+
+    from raymond_amd import scenes, shard
+    from raymond_amd.scene import Settings, generate_tiles
+
+    out_path = str(tmp_path / "reduced.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    st = Settings(scenes.camera(160, 96), sample_count=3, tile_size=(32, 32), bounce_limit=4, seed=21)
+    tiles = generate_tiles(160, 96, st.tile_size)
+    full = oracle.OracleScene(scenes.reflective_spheres()).render_tiles(st.camera_settings, st, tiles, threads=2)
+    assert np.load(out_path).tobytes() == full.tobytes()
+    # the partition itself: disjoint, complete, balanced to within one tile
+    shares = [shard.shard_tiles(tiles, r, world) for r in range(world)]
+    assert sorted(sum(shares, [])) == sorted(tiles)
+    assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+
+
+def test_tile_generation_order_matches_render_tiled():
+    """src/trace.rs:142-173: y advances first, then x (column-major); edge tiles are clamped."""
+    from raymond_amd.scene import generate_tiles
+
+    t = generate_tiles(70, 50, (32, 32))
+    assert t == [(0, 0, 32, 32), (0, 32, 32, 18), (32, 0, 32, 32), (32, 32, 32, 18), (64, 0, 6, 32), (64, 32, 6, 18)]
+    assert len(generate_tiles(1920, 1080, (32, 32))) == 60 * 34
+    assert generate_tiles(32, 32, (32, 32)) == [(0, 0, 32, 32)]
+
+
+def test_shard_rejects_bad_rank():
+    from raymond_amd import shard
+
+    with pytest.raises(ValueError):
+        shard.shard_tiles([(0, 0, 1, 1)], 2, 2)

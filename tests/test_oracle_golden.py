@@ -1,0 +1,271 @@
+"""CPU suite: the oracle against its pins (no GPU).
+
+The reference ships no tests or golden vectors for this path, so the pins are
+  * the Random123 known-answer vectors for Philox4x32-10 (published with the algorithm);
+  * hand-derived known answers of the primitives (closed-form cases);
+  * the committed oracle fixtures under tests/golden/ (regression pins: the oracle today == the oracle that
+    produced the fixtures the GPU path is compared with);
+  * the reference's own render examples/ReflectiveSpheres.png, as 8x8 block means (statistical pin of the
+    whole restatement: scene reconstruction, camera, BRDF, sampling, tone-map).
+Cross-host tolerance: the oracle calls the host libm (sin, cos, acos, pow, tan); glibc selects FMA / non-FMA
+variants per CPU, so fixture comparisons allow 1e-12 relative instead of demanding bit equality.
+"""
+import ctypes as C
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from raymond_amd import scenes
+from raymond_amd.scene import Settings, generate_tiles
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def close(a, b, rtol=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all((np.abs(a - b) <= rtol * np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-300)) | (a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+# ------------------------------------------------------------------ RNG
+def test_philox_random123_known_answers(oracle):
+    L = oracle.load()
+    vectors = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for ctr, key, expect in vectors:
+        c, k, o = np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+        L.orc_philox4x32_10(oracle.ptr(c), oracle.ptr(k), oracle.ptr(o))
+        assert o.tolist() == expect
+
+
+def test_uniform_definition(oracle):
+    """u = ((hi << 32 | lo) >> 11) * 2^-53 with (w1:w0) for even draws, (w3:w2) for odd; counter (pixel, sample, draw >> 1, 0)."""
+    L = oracle.load()
+    seed, pixel, sample = 0x0123456789ABCDEF, 777, 42
+    for draw in range(6):
+        c = np.array([pixel, sample, draw >> 1, 0], dtype=np.uint32)
+        k = np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint32)
+        w = np.zeros(4, dtype=np.uint32)
+        L.orc_philox4x32_10(oracle.ptr(c), oracle.ptr(k), oracle.ptr(w))
+        lo, hi = (int(w[2]), int(w[3])) if draw & 1 else (int(w[0]), int(w[1]))
+        assert L.orc_uniform(seed, pixel, sample, draw) == ((hi << 32 | lo) >> 11) * 2.0**-53
+
+
+# ------------------------------------------------------------------ closed-form known answers
+def _hit(oracle, name, shape, ray):
+    L = oracle.load()
+    s, r = np.array(shape, dtype=np.float64), np.array(ray, dtype=np.float64)
+    hit, t = np.zeros(1, dtype=np.int32), np.zeros(1)
+    getattr(L, "orc_%s_intersect" % name)(1, oracle.ptr(s), oracle.ptr(r), oracle.ptr(hit), oracle.ptr(t))
+    return int(hit[0]), float(t[0])
+
+
+def test_primitive_known_answers(oracle):
+    # sphere.rs:11-27 — unit sphere at z=5 seen from the origin: near root at 4; from inside: miss (Q10)
+    assert _hit(oracle, "sphere", [0, 0, 5, 1], [0, 0, 0, 0, 0, 1]) == (1, 4.0)
+    assert _hit(oracle, "sphere", [0, 0, 5, 1], [0, 0, 5, 0, 0, 1])[0] == 0
+    assert _hit(oracle, "sphere", [0, 0, 5, 1], [0, 0, 0, 0, 0, -1])[0] == 0
+    assert _hit(oracle, "sphere", [0, 2, 5, 1], [0, 0, 0, 0, 0, 1])[0] == 0
+    # plane.rs:11-24 — floor y=-1 facing up: hit from above at t=1, invisible from below (Q11), parallel ray misses
+    assert _hit(oracle, "plane", [0, -1, 0, 0, 1, 0], [0, 0, 0, 0, -1, 0]) == (1, 1.0)
+    assert _hit(oracle, "plane", [0, -1, 0, 0, 1, 0], [0, -2, 0, 0, 1, 0])[0] == 0
+    assert _hit(oracle, "plane", [0, -1, 0, 0, 1, 0], [0, 0, 0, 1, 0, 0])[0] == 0
+    # aabb.rs:10-31 — returns tmin, negative when the origin is inside
+    assert _hit(oracle, "aabb", [-1, -1, 2, 1, 1, 4], [0, 0, 0, 0, 0, 1]) == (1, 2.0)
+    assert _hit(oracle, "aabb", [-1, -1, 2, 1, 1, 4], [0, 0, 3, 0, 0, 1]) == (1, -1.0)
+    assert _hit(oracle, "aabb", [-1, -1, 2, 1, 1, 4], [0, 0, 5, 0, 0, 1])[0] == 0
+    # triangle.rs:11-44 — two-sided Moeller-Trumbore, t > 1e-8
+    tri = [-1, -1, 3, 1, -1, 3, 0, 1, 3]
+    assert _hit(oracle, "triangle", tri, [0, 0, 0, 0, 0, 1]) == (1, 3.0)
+    assert _hit(oracle, "triangle", tri, [0, 0, 6, 0, 0, -1]) == (1, 3.0)
+    assert _hit(oracle, "triangle", tri, [0, 0, 3, 0, 0, 1])[0] == 0  # t = 0 is not > EPSILON
+    assert _hit(oracle, "triangle", tri, [5, 0, 0, 0, 0, 1])[0] == 0
+
+
+def test_sampler_known_answers(oracle):
+    L = oracle.load()
+    # trace.rs:396-406 (Q2): r1 = 1 -> theta = 0 -> straight up (0,1,0), pdf 1;  r1 = 0.25 -> pdf 0.5, cos(theta) = 0.5
+    r1, r2 = np.array([1.0, 0.25]), np.array([0.0, 0.0])
+    d, pdf = np.zeros((2, 3)), np.zeros(2)
+    L.orc_cosine_hemisphere(2, oracle.ptr(r1), oracle.ptr(r2), oracle.ptr(d), oracle.ptr(pdf))
+    assert pdf.tolist() == [1.0, 0.5]
+    assert np.allclose(d[0], [0, 1, 0], atol=1e-16) and abs(d[1, 1] - 0.5) < 1e-15 and abs(d[1, 0] - math.sqrt(0.75)) < 1e-15
+    # trace.rs:408-416: ONB of +z and of -z (sign switch), orthonormal in general
+    n = np.array([[0, 0, 1.0], [0, 0, -1.0], [0.6, 0.0, 0.8]])
+    t, b = np.zeros((3, 3)), np.zeros((3, 3))
+    L.orc_onb(3, oracle.ptr(n), oracle.ptr(t), oracle.ptr(b))
+    assert t[0].tolist() == [1.0, 0.0, -0.0] and b[0].tolist() == [0.0, 1.0, -0.0]
+    assert abs(np.dot(t[2], n[2])) < 1e-15 and abs(np.dot(b[2], n[2])) < 1e-15 and abs(np.dot(t[2], b[2])) < 1e-15
+    # trace.rs:384-386: F(cos=1) = F0, F(cos=0) = 1
+    cos_t, f0 = np.array([1.0, 0.0]), np.array([[0.04, 0.5, 1.0], [0.04, 0.5, 1.0]])
+    F = np.zeros((2, 3))
+    L.orc_fresnel_schlick(2, oracle.ptr(cos_t), oracle.ptr(f0), oracle.ptr(F))
+    assert F[0].tolist() == [0.04, 0.5, 1.0] and F[1].tolist() == [1.0, 1.0, 1.0]
+    # trace.rs:362-370 (Q4): D(n=h) = a2 / (pi * a2^2) with a2 = roughness^2
+    nn, rough, D = np.array([[0, 0, 1.0]]), np.array([0.5]), np.zeros(1)
+    L.orc_ggx_distribution(1, oracle.ptr(nn), oracle.ptr(nn), oracle.ptr(rough), oracle.ptr(D))
+    assert abs(D[0] - 0.25 / (math.pi * 0.25 * 0.25)) < 1e-15
+
+
+def test_emissive_ceiling_pixel_matches_reference_png(oracle):
+    """A primary ray that sees only the ceiling returns its emission 1.5 exactly (trace.rs:250-252); tone-mapped
+    (cli_old/src/main.rs:161-181) that is trunc(255*(1-e^-1.5)^(1/2.2)) = 227 — the value of the ceiling pixels in
+    examples/ReflectiveSpheres.png."""
+    st = Settings(scenes.camera(592, 340), sample_count=1, bounce_limit=5, seed=1)
+    osc = oracle.OracleScene(scenes.reflective_spheres())
+    rgb, po, ps = osc.trace_sample_path(st.camera_settings, st, 296, 2, 0)
+    assert rgb.tolist() == [1.5, 1.5, 1.5] and po.tolist() == [3]
+    assert int(255 * (1 - math.exp(-1.5)) ** (1 / 2.2)) == 227
+    blocks = np.load(os.path.join(GOLD, "png_blocks.npy"))
+    assert abs(blocks[0, 37].mean() - 227) < 0.51
+
+
+# ------------------------------------------------------------------ regression pins (committed fixtures)
+@pytest.fixture(scope="module")
+def kat():
+    return np.load(os.path.join(GOLD, "kat_functions.npz"))
+
+
+def test_function_fixtures(oracle, kat):
+    L = oracle.load()
+    P = oracle.ptr
+    n = 256
+    for name, key in (("sphere", "sphere"), ("plane", "plane"), ("aabb", "aabb"), ("triangle", "triangle")):
+        hit, t = np.zeros(n, dtype=np.int32), np.zeros(n)
+        getattr(L, "orc_%s_intersect" % name)(n, P(kat[key + "_in"]), P(kat[key + "_rays"]), P(hit), P(t))
+        assert np.array_equal(hit, kat[key + "_hit"]) and 0 < hit.sum() < n
+        assert close(t[hit == 1], kat[key + "_t"][hit == 1], 1e-15)
+    o = np.zeros((n, 3))
+    L.orc_triangle_normal(n, P(kat["trinrm_pos"]), P(kat["trinrm_nrm"]), P(kat["trinrm_rays"]), P(kat["trinrm_t"]), P(o))
+    assert close(o, kat["trinrm_out"], 1e-15)
+    d, pdf = np.zeros((n, 3)), np.zeros(n)
+    L.orc_cosine_hemisphere(n, P(kat["cos_r1"]), P(kat["cos_r2"]), P(d), P(pdf))
+    assert np.abs(d - kat["cos_dir"]).max() < 1e-15 and close(pdf, kat["cos_pdf"], 1e-16)
+    g = np.zeros((n, 3))
+    L.orc_importance_sample_ggx(n, P(kat["ggx_reflect"]), P(kat["ggx_rough"]), P(kat["cos_r1"]), P(kat["cos_r2"]), P(g))
+    assert np.abs(g - kat["ggx_dir"]).max() < 1e-14
+    D, G = np.zeros(n), np.zeros(n)
+    L.orc_ggx_distribution(n, P(kat["brdf_n"]), P(kat["brdf_h"]), P(kat["ggx_rough"]), P(D))
+    L.orc_geometry_smith(n, P(kat["brdf_n"]), P(kat["brdf_v"]), P(kat["brdf_l"]), P(kat["ggx_rough"]), P(G))
+    assert close(D, kat["brdf_D"], 1e-15) and close(G, kat["brdf_G"], 1e-15)
+    F = np.zeros((n, 3))
+    L.orc_fresnel_schlick(n, P(kat["fresnel_cos"]), P(kat["fresnel_f0"]), P(F))
+    assert close(F, kat["fresnel_out"], 1e-13)
+    u = np.array([L.orc_uniform(scenes.SEED, int(p), int(s), int(d_)) for p, s, d_ in zip(kat["rng_pixel"], kat["rng_sample"], kat["rng_draw"])])
+    assert np.array_equal(u, kat["rng_u"])
+    pr = np.zeros((n, 6))
+    cp = scenes.camera(1920, 1080).pod()
+    L.orc_primary_ray(n, C.byref(cp), P(kat["pray_xy"]), P(kat["pray_u"]), P(pr))
+    assert close(pr, kat["pray_out"], 1e-15)
+
+
+def _check_paths(oracle, scene, settings, fname):
+    f = np.load(os.path.join(GOLD, fname))
+    osc = oracle.OracleScene(scene)
+    cam = settings.camera_settings
+    same = 0
+    n = len(f["sample"])
+    for i in range(n):
+        rgb, po, ps = osc.trace_sample_path(cam, settings, int(f["xy"][i, 0]), int(f["xy"][i, 1]), int(f["sample"][i]))
+        epo = f["path_obj"][i]
+        k = int((epo != -2).sum())
+        if len(po) == k and np.array_equal(po, epo[:k]) and np.array_equal(ps, f["path_sub"][i][:k]):
+            same += 1
+            assert close(rgb, f["rgb"][i], 1e-10)
+    assert same >= n - 2  # a different libm variant may flip a borderline sample; never more than a couple
+    assert (f["rgb"] > 0).any(axis=1).mean() > 0.05
+
+
+def test_path_fixtures_spheres(oracle):
+    _check_paths(oracle, scenes.reflective_spheres(), scenes.config_settings("C1"), "paths_spheres.npz")
+
+
+def test_path_fixtures_mesh(oracle):
+    sc = scenes.gold_dragon_standin(n=24, grid_builder=lambda m: oracle.grid_build(m)[1])
+    _check_paths(oracle, sc, Settings(scenes.camera(480, 270), sample_count=1, bounce_limit=5, seed=scenes.SEED), "paths_mesh.npz")
+    f = np.load(os.path.join(GOLD, "paths_mesh.npz"))
+    assert (f["path_obj"] == 1).any(axis=1).mean() > 0.1  # the mesh (object 1) is on a good share of the paths
+
+
+def test_config1_image_fixture(oracle):
+    """BASELINE.json configs[0]: ReflectiveSpheres 256x256, 16 spp, 3 bounces on the CPU path."""
+    f = np.load(os.path.join(GOLD, "image_c1.npz"))
+    sc, st = scenes.reflective_spheres(), scenes.config_settings("C1")
+    img = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, generate_tiles(256, 256, st.tile_size))
+    tiles = img.reshape(8, 32, 8, 32, 3).sum(axis=(1, 3))
+    assert np.allclose(tiles, f["tile_sums"], rtol=2e-3, atol=1e-9)  # a flipped sample moves one tile sum slightly
+    crop_ok = np.isclose(img[96:160, 96:160], f["crop"], rtol=1e-10, atol=0).all(axis=2) | (img[96:160, 96:160] == f["crop"]).all(axis=2)
+    assert crop_ok.mean() > 0.999
+    if hashlib.sha256(img.tobytes()).digest() != f["sha256"].tobytes():
+        print("note: config-1 image differs in its last bits from the committed digest (different libm variant)")
+
+
+def test_render_is_deterministic_and_thread_count_independent(oracle):
+    sc = scenes.reflective_spheres()
+    st = Settings(scenes.camera(96, 64), sample_count=5, bounce_limit=4, seed=9)
+    tiles = generate_tiles(96, 64, (32, 32))
+    osc = oracle.OracleScene(sc)
+    a = osc.render_tiles(st.camera_settings, st, tiles, threads=1)
+    b = osc.render_tiles(st.camera_settings, st, tiles, threads=7)
+    assert a.tobytes() == b.tobytes()
+    # progressive passes == single pass
+    c = osc.render_tiles(st.camera_settings, st, tiles, sample_begin=0, sample_count=2, threads=3)
+    c = osc.render_tiles(st.camera_settings, st, tiles, accum=c, sample_begin=2, sample_count=3, threads=3)
+    assert c.tobytes() == a.tobytes()
+
+
+def test_grid_digest_fixtures(oracle):
+    with open(os.path.join(GOLD, "grid_digests.json")) as f:
+        digests = json.load(f)
+    for n in (13, 40):
+        mesh = scenes.lumpy_sphere_mesh(n)
+        mesh.bake_transform((0.0, -0.3, 2.9))
+        d = digests[str(n)]
+        assert hashlib.sha256(mesh.tri_pos.tobytes()).hexdigest() == d["tri_pos_sha256"]  # IEEE-exact generator
+        rc, g = oracle.grid_build(mesh)
+        assert rc == 0 and [int(v) for v in g.resolution] == d["resolution"]
+        assert hashlib.sha256(g.cells.tobytes()).hexdigest() == d["cells_sha256"]
+        assert hashlib.sha256(g.mapping_table.tobytes()).hexdigest() == d["mapping_sha256"]
+
+
+def test_work_counters_fixture(oracle):
+    """The counters behind bench.py's algorithmic-bytes figure: re-count config 1."""
+    with open(os.path.join(GOLD, "work_counters.json")) as f:
+        wc = json.load(f)
+    sc, st = scenes.reflective_spheres(), scenes.config_settings("C1")
+    oracle.counters_reset()
+    oracle.OracleScene(sc).render_tiles(st.camera_settings, st, generate_tiles(256, 256, st.tile_size))
+    c = oracle.counters()
+    for k in ("samples", "segments", "bounces", "draws"):
+        assert abs(c[k] - wc["C1"][k]) <= 1e-4 * wc["C1"][k]
+    c3 = wc["C3"]
+    assert c3["samples"] == 1920 * 1080 * 2 and c3["cells"] > 10 * c3["samples"] and c3["tri_tests"] > c3["cells"]
+
+
+# ------------------------------------------------------------------ the reference's own render
+def test_statistical_match_with_reference_png(oracle):
+    """592x340, 5 bounces as in README.md:24; 48 spp here vs the PNG's 500 — compare tone-mapped 8x8 block means."""
+    blocks_ref = np.load(os.path.join(GOLD, "png_blocks.npy")).astype(np.float64)
+    st = Settings(scenes.camera(592, 340), sample_count=48, tile_size=(32, 32), bounce_limit=5, seed=scenes.SEED)
+    img = oracle.OracleScene(scenes.reflective_spheres()).render_tiles(st.camera_settings, st, generate_tiles(592, 340, (32, 32))) / 48.0
+    tm = np.trunc(255.0 * np.power(1.0 - np.exp(-img), 1.0 / 2.2))
+    blocks = tm[:336].reshape(42, 8, 74, 8, 3).mean(axis=(1, 3))
+    d = np.abs(blocks - blocks_ref)
+    assert d.mean() < 2.5, d.mean()  # measured 1.5 of 255 at 64 spp
+    assert np.percentile(d, 99) < 12.0
+    assert abs(blocks.mean() - blocks_ref.mean()) < 3.0
+    # both spheres sit where the PNG has them: red-dominant and blue-dominant block centroids within 1.5 blocks
+    for ch, other in ((0, 2), (2, 0)):
+        def centroid(b):
+            m = (b[:, :, ch] > 1.6 * b[:, :, other] + 20) & (b[:, :, ch] > 1.6 * b[:, :, 1])
+            ys, xs = np.nonzero(m)
+            return np.array([xs.mean(), ys.mean()]), m.sum()
+        (c_ref, n_ref), (c_our, n_our) = centroid(blocks_ref), centroid(blocks)
+        assert n_ref > 10 and abs(n_our - n_ref) <= 0.35 * n_ref
+        assert np.abs(c_ref - c_our).max() < 1.5
