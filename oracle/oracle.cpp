@@ -67,6 +67,10 @@ enum { K_SAMPLES, K_SEGMENTS, K_CELLS, K_TRI_TESTS, K_MESH_HITS, K_BOUNCES, K_DR
 std::mutex g_counter_mutex;
 Counters g_counters;
 thread_local Counters tl_counters;
+/* per-walk histograms (design instrumentation): [kind][bucket], kind 0 = cells visited, 1 = non-empty cells visited, 2 = triangle tests, 3 = max triangles in one cell */
+std::atomic<uint64_t> g_walk_hist[4][65];
+std::atomic<uint64_t> g_walk_hits{0};
+inline void hist_add(int kind, uint64_t v) { g_walk_hist[kind][v > 64 ? 64 : v]++; }
 void flush_counters() {
 	std::lock_guard<std::mutex> lock(g_counter_mutex);
 	for (int i = 0; i < 8; i++) {
@@ -367,6 +371,12 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 	double t_max_z = (((double)(cz + (ray.direction.z < 0.0 ? 0 : 1)) * g.cell_size.z) - start.z) / ray.direction.z;
 
 	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
+	uint64_t w_cells = 0, w_nonempty = 0, w_tests = 0, w_maxc = 0;
+	struct WalkStat {
+		uint64_t &c, &n, &t, &m;
+		bool hit = false;
+		~WalkStat() { hist_add(0, c), hist_add(1, n), hist_add(2, t), hist_add(3, m); if (hit) g_walk_hits++; }
+	} wstat{w_cells, w_nonempty, w_tests, w_maxc};
 	for (;;) {
 		/* `as usize` of a negative i32 sign-extends; the index arithmetic wraps (release build) */
 		uint64_t x = (uint64_t)(int64_t)cx, y = (uint64_t)(int64_t)cy, z = (uint64_t)(int64_t)cz;
@@ -375,6 +385,7 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 		tl_counters.c[K_CELLS]++;
 		uint64_t cell = g.cells[idx];
 		uint64_t count = g.mapping_table[cell];
+		w_cells++, w_tests += count, w_nonempty += count > 0, w_maxc = std::max(w_maxc, count);
 		double closest = 5712515.0;
 		Hit closest_hit = hit_none();
 		for (uint64_t i = 1; i <= count; i++) {
@@ -388,7 +399,10 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 				}
 			}
 		}
-		if (closest_hit.some) return closest_hit; /* Q7: first cell with any hit wins */
+		if (closest_hit.some) {
+			wstat.hit = true;
+			return closest_hit; /* Q7: first cell with any hit wins */
+		}
 
 		if (t_max_x < t_max_y) {
 			if (t_max_x < t_max_z) {
@@ -894,7 +908,15 @@ void orc_render_tiles(const orc_scene *s, const rmd_camera *cam, const rmd_setti
 	for (auto &t : pool) t.join();
 }
 
+void orc_walk_hist(uint64_t out[4 * 65 + 1]) {
+	for (int k = 0; k < 4; k++)
+		for (int b = 0; b < 65; b++) out[k * 65 + b] = g_walk_hist[k][b].load();
+	out[4 * 65] = g_walk_hits.load();
+}
 void orc_counters_reset(void) {
+	for (int k = 0; k < 4; k++)
+		for (int b = 0; b < 65; b++) g_walk_hist[k][b] = 0;
+	g_walk_hits = 0;
 	flush_counters();
 	std::lock_guard<std::mutex> lock(g_counter_mutex);
 	g_counters = Counters();

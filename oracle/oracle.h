@@ -84,6 +84,8 @@ void orc_render_tiles(const orc_scene *s, const rmd_camera *cam, const rmd_setti
  * [0] samples, [1] path segments (Scene::intersect calls), [2] grid cells visited, [3] triangle tests,
  * [4] mesh hits shaded (Triangle::get_surface_properties calls), [5] shaded bounces, [6] rng draws, [7] grid walks */
 void orc_counters_reset(void);
+/* per-walk histograms, buckets 0..63 and 64+ : cells visited, non-empty cells visited, triangle tests, max triangles per cell; [260] = walks that hit */
+void orc_walk_hist(uint64_t out[4 * 65 + 1]);
 void orc_counters_get(uint64_t out[8]);
 
 #ifdef __cplusplus

@@ -105,7 +105,7 @@ rmd_status check_render_args(rmd_context *ctx, const rmd_scene *scene, const rmd
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: backbuffer size must be 1..65535 per axis");
 	if (st->bounce_limit > RMD_MAX_BOUNCE_LIMIT) return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: bounce_limit above RMD_MAX_BOUNCE_LIMIT");
 	if ((uint64_t)st->sample_begin + st->sample_count > 0xFFFFFFFFull) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: sample range overflows u32");
-	if (rmd::render_lds_bytes(scene->n_objects, st->bounce_limit) > 160u * 1024u)
+	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, st->bounce_limit, 1) > rmd::kLdsBudgetBytes)
 		return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: object table + bounce stack exceed the 160 KiB LDS of a CU");
 	return RMD_OK;
 }
@@ -136,6 +136,8 @@ RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rm
 	P.bounce_limit = st->bounce_limit;
 	P.sample_begin = st->sample_begin, P.sample_count = st->sample_count;
 	P.n_objects = scene ? scene->n_objects : 0;
+	P.n_grids = scene ? scene->n_grids : 0;
+	P.mask_words_total = scene ? scene->mask_words_total : 0;
 	P.key0 = (uint32_t)st->seed, P.key1 = (uint32_t)(st->seed >> 32);
 	P.use_dof = cam->aperture_radius > 0.0 ? 1u : 0u;
 	return P;
@@ -235,20 +237,53 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 			d.res[a] = g.resolution[a];
 		}
 		d.n_cells = g.n_cells, d.n_tris = g.n_tris;
-		// intersection records: v0, edge1 = v1 - v0, edge2 = v2 - v0 (triangle.rs:16-17, same subtraction, done once)
-		std::vector<double> isect(g.n_tris * 9);
-		for (uint64_t t = 0; t < g.n_tris; t++) {
-			const double *p = g.tri_pos + t * 9;
-			double *q = isect.data() + t * 9;
-			for (int a = 0; a < 3; a++) q[a] = p[a], q[3 + a] = p[3 + a] - p[a], q[6 + a] = p[6 + a] - p[a];
+		// cell entries + contiguous per-cell triangle runs (device_types.hpp): record = v0, edge1 = v1 - v0, edge2 = v2 - v0
+		// (triangle.rs:16-17, same subtraction, done once), triangle index, pad — in mapping_table order
+		const uint64_t n_refs = g.n_mapping - g.n_cells;
+		if (n_refs > 0xFFFFFFFFull) {
+			rmd_scene_destroy(sc);
+			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: more than 2^32-1 cell->triangle references");
 		}
+		std::vector<rmd::CellEntry> entries(g.n_cells);
+		std::vector<unsigned char> runs((size_t)n_refs * 80u, 0);
+		uint64_t next = 0, last_nonempty = 0;
+		bool any_nonempty = false;
+		for (uint64_t c = 0; c < g.n_cells; c++) {
+			const uint32_t off = g.cells[c], cnt = g.mapping_table[off];
+			entries[c].first = (uint32_t)next, entries[c].count = cnt;
+			if (cnt) last_nonempty = c, any_nonempty = true;
+			for (uint32_t k = 1; k <= cnt; k++) {
+				if (next >= n_refs) { // cells sharing a run: the tables are not the builder's; refuse rather than overflow
+					rmd_scene_destroy(sc);
+					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table runs overlap");
+				}
+				const uint32_t ti = g.mapping_table[off + k];
+				const double *p = g.tri_pos + (size_t)ti * 9;
+				double *q = reinterpret_cast<double *>(runs.data() + (size_t)next * 80u);
+				for (int a = 0; a < 3; a++) q[a] = p[a], q[3 + a] = p[3 + a] - p[a], q[6 + a] = p[6 + a] - p[a];
+				reinterpret_cast<uint32_t *>(q)[18] = ti;
+				next++;
+			}
+		}
+		// occupancy bitmask for LDS: bit i covers cells [i << shift, (i+1) << shift); only up to the last non-empty cell
+		const uint64_t covered = any_nonempty ? last_nonempty + 1 : 0;
+		const size_t budget_words = rmd::kMaskBudgetBytes / 4 / n_grids;
+		uint32_t shift = 0;
+		while (((covered >> shift) + 31) / 32 > budget_words) shift++;
+		const uint64_t bits = covered ? ((covered - 1) >> shift) + 1 : 0;
+		std::vector<uint32_t> mask((size_t)((bits + 31) / 32) + (bits == 0 ? 1 : 0), 0u);
+		for (uint64_t c = 0; c < covered; c++)
+			if (entries[c].count) mask[(c >> shift) >> 5] |= 1u << ((c >> shift) & 31u);
+		d.mask_bits = (uint32_t)bits, d.mask_shift = shift, d.mask_n_words = (uint32_t)mask.size();
+		d.mask_lds_word = sc->mask_words_total;
+		sc->mask_words_total += (uint32_t)((mask.size() + 3) & ~(size_t)3);
 		void *p = nullptr;
-		RMD_SCENE_HIP(upload(g.cells, g.n_cells * sizeof(uint32_t), &p));
-		d.cells = (const uint32_t *)p;
-		RMD_SCENE_HIP(upload(g.mapping_table, g.n_mapping * sizeof(uint32_t), &p));
-		d.mapping_table = (const uint32_t *)p;
-		RMD_SCENE_HIP(upload(isect.data(), isect.size() * sizeof(double), &p));
-		d.tri_isect = (const double *)p;
+		RMD_SCENE_HIP(upload(entries.data(), entries.size() * sizeof(rmd::CellEntry), &p));
+		d.cell_entries = (const rmd::CellEntry *)p;
+		RMD_SCENE_HIP(upload(runs.data(), runs.size(), &p));
+		d.tri_runs = p;
+		RMD_SCENE_HIP(upload(mask.data(), mask.size() * sizeof(uint32_t), &p));
+		d.mask_words = (const uint32_t *)p;
 		RMD_SCENE_HIP(upload(g.tri_pos, g.n_tris * 9 * sizeof(double), &p));
 		d.tri_pos = (const double *)p;
 		RMD_SCENE_HIP(upload(g.tri_nrm, g.n_tris * 9 * sizeof(double), &p));

@@ -153,113 +153,6 @@ RMD_DEV bool cast_i32(double v, int32_t &out) {
 	return true;
 }
 
-// core/src/geometry/acc_grid.rs:89-185: 3D-DDA walk, closest hit of the first cell that yields any hit.
-// Where the reference would panic (a failed i32 cast, :94,:98,:102) this reports a miss.
-RMD_DEV bool grid_intersect(const DevGrid &g, V3 ro, V3 rd, double &t_out, uint32_t &tri_out) {
-	V3 bmin = ld3(g.bbox_min);
-	double t_outer;
-	if (!aabb_intersect(bmin, ld3(g.bbox_max), ro, rd, t_outer)) return false;
-	V3 cs = ld3(g.cell_size);
-	V3 start = ro - bmin;
-	int32_t cx, cy, cz;
-	if (!cast_i32(start.x / cs.x, cx) || !cast_i32(start.y / cs.y, cy) || !cast_i32(start.z / cs.z, cz)) return false;
-	if (cx < 0 || cy < 0 || cz < 0) {
-		V3 outer_pos = ro + rd * t_outer;
-		start = outer_pos - bmin;
-		if (!cast_i32(start.x / cs.x, cx) || !cast_i32(start.y / cs.y, cy) || !cast_i32(start.z / cs.z, cz)) return false;
-	}
-	if (rd.x != rd.x || rd.y != rd.y || rd.z != rd.z) return false; // signum(NaN).cast::<i32>() panics
-	const int32_t sx = signbit(rd.x) ? -1 : 1, sy = signbit(rd.y) ? -1 : 1, sz = signbit(rd.z) ? -1 : 1;
-
-	const double t_delta_x = (rd.x < 0.0 ? -cs.x : cs.x) / rd.x;
-	const double t_delta_y = (rd.y < 0.0 ? -cs.y : cs.y) / rd.y;
-	const double t_delta_z = (rd.z < 0.0 ? -cs.z : cs.z) / rd.z;
-	double t_max_x = (((double)(cx + (rd.x < 0.0 ? 0 : 1)) * cs.x) - start.x) / rd.x;
-	double t_max_y = (((double)(cy + (rd.y < 0.0 ? 0 : 1)) * cs.y) - start.y) / rd.y;
-	double t_max_z = (((double)(cz + (rd.z < 0.0 ? 0 : 1)) * cs.z) - start.z) / rd.z;
-
-	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
-	const uint32_t *__restrict__ cells = g.cells;
-	const uint32_t *__restrict__ map = g.mapping_table;
-	const double *__restrict__ tris = g.tri_isect;
-	for (;;) {
-		// `as usize` sign-extends, the index arithmetic wraps (release build); Q5: res.z where res.y is meant
-		uint64_t idx = (uint64_t)(int64_t)cx + g.res[0] * ((uint64_t)(int64_t)cy + (uint64_t)(int64_t)cz * g.res[2]);
-		if (idx >= g.n_cells) return false;
-		uint32_t cell = cells[idx];
-		uint32_t count = map[cell];
-		double closest = 5712515.0;
-		bool any = false;
-		uint32_t best_tri = 0;
-		for (uint32_t i = 1; i <= count; i++) {
-			uint32_t ti = map[cell + i];
-			const double *tp = tris + (size_t)ti * 9;
-			double t;
-			if (triangle_intersect(ld3(tp), ld3(tp + 3), ld3(tp + 6), ro, rd, t)) {
-				if (t < closest) {
-					closest = t;
-					best_tri = ti;
-					any = true;
-				}
-			}
-		}
-		if (any) {
-			t_out = closest;
-			tri_out = best_tri;
-			return true;
-		}
-		if (t_max_x < t_max_y) {
-			if (t_max_x < t_max_z) {
-				cx += sx;
-				if (cx >= rx || cx < 0) return false;
-				t_max_x += t_delta_x;
-			} else {
-				cz += sz;
-				if (cz >= rz || cz < 0) return false;
-				t_max_z += t_delta_z;
-			}
-		} else {
-			if (t_max_y < t_max_z) {
-				cy += sy;
-				if (cy >= ry || cy < 0) return false;
-				t_max_y += t_delta_y;
-			} else {
-				cz += sz;
-				if (cz >= rz || cz < 0) return false;
-				t_max_z += t_delta_z;
-			}
-		}
-	}
-}
-
-// core/src/scene.rs:54-74: linear closest hit; strict '<' keeps the first object on ties.
-// `objs` is indexed uniformly across the wave, so the fetches are scalar loads.
-RMD_DEV int scene_intersect(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, V3 ro,
-                            V3 rd, double &t_best, uint32_t &sub_best) {
-	double closest = kFMax;
-	int best = -1;
-	uint32_t sub = 0;
-	for (uint32_t i = 0; i < n_objects; i++) {
-		const DevObject &o = objs[i];
-		double t;
-		uint32_t tri = 0;
-		bool hit;
-		if (o.geometry_kind == 0u) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
-		else if (o.geometry_kind == 1u) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
-		else hit = grid_intersect(grids[o.grid_index], ro, rd, t, tri);
-		if (hit) {
-			if (t < closest) {
-				closest = t;
-				best = (int)i;
-				sub = tri;
-			}
-		}
-	}
-	t_best = closest;
-	sub_best = sub;
-	return best;
-}
-
 // ---------------------------------------------------------------- BRDF + samplers (src/trace.rs:362-416)
 RMD_DEV double lerp(double mn, double mx, double a) { return mn + a * (mx - mn); } // :392-394
 // :362-370 — NdotH.powf(2.0) is x*x after LLVM's unconditional pow(x, 2.0) fold

@@ -23,19 +23,33 @@ struct alignas(16) DevObject {
 };
 static_assert(sizeof(DevObject) == 128, "DevObject layout");
 
-// One AccGrid (reference core/src/geometry/acc_grid.rs:27-33).
+// One AccGrid (reference core/src/geometry/acc_grid.rs:27-33), re-laid out at upload for the wave-cooperative walk
+// (grid_walk.hpp).  `cells[c] -> mapping_table[off] = count, idx...` (acc_grid.rs:67-74) becomes
+//   cell_entries[c] = {first record, count}                       one 8-byte gather per candidate cell
+//   tri_runs[first .. first+count)                                 the cell's triangles as CONTIGUOUS 80-byte records,
+//                                                                  in mapping_table order: v0, edge1, edge2 (9 f64), triangle index (u32), pad
+// so a cell's tests read one coalesced run instead of chasing an index per triangle.  A triangle referenced by k cells
+// is stored k times (HBM is 288 GB; the benchmark mesh needs tens of MB).
+struct CellEntry {
+	uint32_t first, count;
+};
+
 struct alignas(16) DevGrid {
 	double bbox_min[3];
 	double bbox_max[3];
 	double cell_size[3];
 	uint64_t res[3];
 	uint64_t n_cells;
-	const uint32_t *cells;         // n_cells offsets into mapping_table
-	const uint32_t *mapping_table; // [count, idx...] runs
-	const double *tri_isect;       // n_tris * 9: v0, edge1 = v1 - v0, edge2 = v2 - v0 (triangle.rs:16-17 hoisted to upload)
-	const double *tri_pos;         // n_tris * 9: v0 v1 v2 (Heron normal, triangle.rs:47-68)
-	const double *tri_nrm;         // n_tris * 9: n0 n1 n2
+	const CellEntry *cell_entries; // n_cells x {first, count}
+	const void *tri_runs;       // n_refs x 80 B
+	const double *tri_pos;      // n_tris * 9: v0 v1 v2 (Heron normal, triangle.rs:47-68)
+	const double *tri_nrm;      // n_tris * 9: n0 n1 n2
+	const uint32_t *mask_words; // occupancy bitmask (global copy, staged into LDS by every workgroup)
 	uint64_t n_tris;
+	uint32_t mask_bits;         // number of valid bits; bit i covers cells [i << mask_shift, (i+1) << mask_shift)
+	uint32_t mask_shift;
+	uint32_t mask_n_words;
+	uint32_t mask_lds_word;     // word offset of this grid's mask inside the LDS mask area, 0xFFFFFFFF = not staged
 };
 
 // 8x8-pixel wave tile: one wavefront, lane = pixel (lane & 7, lane >> 3).
@@ -62,6 +76,8 @@ struct RenderParams {
 	uint32_t key0, key1; // Philox key = seed lo/hi
 	uint32_t n_work;     // wave tiles (tile mode) or list entries (list mode)
 	uint32_t use_dof;
+	uint32_t n_grids;
+	uint32_t mask_words_total; // LDS words reserved for the grids' occupancy masks
 };
 
 // List mode (probe): one lane per explicit (x, y, sample).

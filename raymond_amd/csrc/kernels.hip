@@ -15,56 +15,111 @@
 #include <hip/hip_runtime.h>
 
 #include "device_core.hpp"
+#include "grid_walk.hpp"
 #include "launch.hpp"
 
 namespace rmd {
 
-// LDS stack slot (level, comp, lane), 6 doubles per level (A.xyz, cos, d1, d2): consecutive lanes hit consecutive 8-byte words, so every
-// access is bank-conflict free whatever level each lane is at (levels differ by multiples of 512 B).
-RMD_DEV int stack_slot(uint32_t level, int comp, uint32_t lane) { return (int)((level * 6u + (uint32_t)comp) * 64u + lane); }
+// LDS stack slot (level, comp, lane), 5 doubles per level (A.xyz, cos, d): consecutive lanes hit consecutive 8-byte
+// words, so every access is bank-conflict free whatever level each lane is at (levels differ by multiples of 512 B).
+constexpr uint32_t kStackDoublesPerLevel = 5;
+// LDS per wave: [WalkScratch if the scene has grids][bounce stack]
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t bounce_limit, uint32_t n_grids) {
+	return (n_grids ? sizeof(WalkScratch) : 0) + (size_t)bounce_limit * kStackDoublesPerLevel * 64u * sizeof(double);
+}
+RMD_DEV int stack_slot(uint32_t level, int comp, uint32_t lane) { return (int)((level * kStackDoublesPerLevel + (uint32_t)comp) * 64u + lane); }
 
-// Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs; giving each XCD a
-// contiguous run of wave tiles keeps neighbouring tiles (which walk the same grid cells and
-// triangles) behind one L2.  Bijective for any grid size; affects speed only.
-RMD_DEV uint32_t xcd_remap(uint32_t b, uint32_t nb) {
-	uint32_t xcd = b & 7u, slot = b >> 3;
-	uint32_t q = nb >> 3, r = nb & 7u;
-	uint32_t start = xcd * q + (xcd < r ? xcd : r);
-	return start + slot;
+// Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
+// reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
+// spreads every image region over all 8 XCDs: the mesh region costs ~10x a wall region per tile, and a mapping that
+// hands each XCD one contiguous band of the image leaves most XCDs idle while two or three grind through the mesh
+// (measured: 2x slower).  Balance beats L2 locality here — the scene (tens of MB) lives in L2 + Infinity Cache anyway.
+RMD_DEV uint32_t work_item_of_block(uint32_t b, uint32_t nb) {
+	(void)nb;
+	return b;
+}
+
+// core/src/scene.rs:54-74: linear closest hit over the objects; strict '<' keeps the first object on ties.
+// Wave-level: called by all 64 lanes in uniform control flow, `want` marks the lanes that carry a ray.  The object
+// table is indexed uniformly (scalar loads); planes and spheres are tested per lane, a grid object runs the
+// wave-cooperative walk.
+RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids,
+                                 const uint32_t *lds_masks, WalkScratch &scr, bool want, V3 ro, V3 rd, double &t_best, uint32_t &sub_best) {
+	double closest = kFMax;
+	int best = -1;
+	uint32_t sub = 0;
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const DevObject &o = objs[i];
+		double t = 0.0;
+		uint32_t tri = 0;
+		bool hit = false;
+		if (o.geometry_kind == 0u) {
+			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
+		} else if (o.geometry_kind == 1u) {
+			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
+		} else {
+			const DevGrid &g = grids[o.grid_index];
+			const uint32_t *mask = (lds_masks && g.mask_lds_word != 0xFFFFFFFFu) ? lds_masks + g.mask_lds_word : nullptr;
+			grid_intersect_wave(g, mask, scr, want, ro, rd, hit, t, tri);
+		}
+		if (want && hit) {
+			if (t < closest) {
+				closest = t;
+				best = (int)i;
+				sub = tri;
+			}
+		}
+	}
+	t_best = closest;
+	sub_best = sub;
+	return best;
 }
 
 template <bool LIST>
-__global__ __launch_bounds__(64) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
-                                                    const DevGrid *__restrict__ grids, const void *__restrict__ work,
-                                                    double *__restrict__ out, int32_t *__restrict__ path_obj,
-                                                    uint32_t *__restrict__ path_sub) {
+__global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
+                                                     const DevGrid *__restrict__ grids, const void *__restrict__ work,
+                                                     double *__restrict__ out, int32_t *__restrict__ path_obj,
+                                                     uint32_t *__restrict__ path_sub) {
 	extern __shared__ __align__(16) unsigned char smem[];
+	// LDS: [object table][grid occupancy masks][one bounce stack per wave]
 	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
-	double *stack = reinterpret_cast<double *>(smem + (size_t)P.n_objects * sizeof(DevObject));
-	const uint32_t lane = threadIdx.x;
+	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
+	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
+	                          (size_t)wave * wave_lds_bytes(P.bounce_limit, P.n_grids);
+	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
+	double *stack = reinterpret_cast<double *>(wave_lds + (P.n_grids ? sizeof(WalkScratch) : 0));
 
-	// stage the object table: 16 doubles per object, coalesced
+	// stage the object table and the occupancy masks: coalesced, once per workgroup
 	{
 		const double *src = reinterpret_cast<const double *>(objs);
 		double *dst = reinterpret_cast<double *>(lobjs);
-		for (uint32_t i = lane; i < P.n_objects * 16u; i += 64u) dst[i] = src[i];
+		for (uint32_t i = tid; i < P.n_objects * 16u; i += blockDim.x) dst[i] = src[i];
+		for (uint32_t gi = 0; gi < P.n_grids; gi++) {
+			const DevGrid &g = grids[gi];
+			if (g.mask_lds_word == 0xFFFFFFFFu) continue;
+			for (uint32_t i = tid; i < g.mask_n_words; i += blockDim.x) lmasks[g.mask_lds_word + i] = g.mask_words[i];
+		}
 	}
-	__syncthreads();
+	__syncthreads(); // the only workgroup barrier: from here on every wave runs on its own
+	const uint32_t *lds_masks = P.mask_words_total ? lmasks : nullptr;
 
 	uint32_t x, y, s, s_end;
 	bool alive;
 	size_t out_index;
+	uint32_t list_idx = 0;
 	if (LIST) {
-		uint32_t idx = blockIdx.x * 64u + lane;
-		alive = idx < P.n_work;
-		ListWork w = reinterpret_cast<const ListWork *>(work)[alive ? idx : 0];
+		list_idx = (blockIdx.x * waves_per_wg + wave) * 64u + lane;
+		alive = list_idx < P.n_work;
+		ListWork w = reinterpret_cast<const ListWork *>(work)[alive ? list_idx : 0];
 		x = w.x, y = w.y, s = w.sample, s_end = w.sample + 1u;
-		out_index = (size_t)idx * 3;
+		out_index = (size_t)list_idx * 3;
 	} else {
-		uint32_t wt = xcd_remap(blockIdx.x, gridDim.x);
-		WaveTile t = reinterpret_cast<const WaveTile *>(work)[wt];
+		uint32_t wt = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
+		bool have = wt < P.n_work;
+		WaveTile t = reinterpret_cast<const WaveTile *>(work)[have ? wt : 0];
 		uint32_t lx = lane & 7u, ly = lane >> 3;
-		alive = lx < t.w && ly < t.h && P.sample_count > 0u;
+		alive = have && lx < t.w && ly < t.h && P.sample_count > 0u;
 		x = t.x0 + lx, y = t.y0 + ly;
 		s = P.sample_begin, s_end = P.sample_begin + P.sample_count;
 		out_index = ((size_t)x + (size_t)y * P.W) * 3;
@@ -77,16 +132,20 @@ __global__ __launch_bounds__(64) void render_kernel(RenderParams P, const DevObj
 
 	const V3 cam_pos = ld3(P.cam_pos);
 	Rng rng;
+	rng.init(P.key0, P.key1, pixel, s);
 	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
-	uint32_t depth = 1;      // depth argument of the trace() call being evaluated
-	uint32_t specmask = 0;   // bit l: stack level l is a specular bounce
+	uint32_t depth = 1;     // depth argument of the trace() call being evaluated
+	uint32_t specmask = 0;  // bit l: stack level l is a specular bounce
+	uint32_t metalmask = 0; // bit l: stack level l hit a Metal material (1 - prob_d = 1.0, else 0.5)
 	uint32_t path_len = 0;
 	bool fresh = true;
 
-	while (alive) {
+	// Wave-uniform main loop: all 64 lanes stay in it until every lane has finished its samples, so that finished
+	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated on `alive`.
+	while (__ballot(alive) != 0ull) {
 		bool terminal = false;
 		V3 L = mk(0.0, 0.0, 0.0);
-		if (fresh) {
+		if (alive && fresh) {
 			// src/trace.rs:199 — primary ray of sample s
 			rng.init(P.key0, P.key1, pixel, s);
 			bool ok = true;
@@ -97,18 +156,19 @@ __global__ __launch_bounds__(64) void render_kernel(RenderParams P, const DevObj
 				primary_ray(P, x, y, u0, u1, ro, rd);
 			}
 			depth = 1;
-			specmask = 0;
+			specmask = 0, metalmask = 0;
 			fresh = false;
 			if (!ok) terminal = true;                  // reference panics here; the sample contributes zero
-			if (P.bounce_limit == 0u) terminal = true; // trace(…, 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237)
+			if (P.bounce_limit == 0u) terminal = true; // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237)
 		}
-		if (!terminal) {
-			// src/trace.rs:239
-			double t;
-			uint32_t sub;
-			int oi = scene_intersect(objs, P.n_objects, grids, ro, rd, t, sub);
+		const bool want = alive && !terminal;
+		// src/trace.rs:239
+		double t;
+		uint32_t sub;
+		const int oi = scene_intersect_wave(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub);
+		if (want) {
 			if (LIST && path_obj) {
-				size_t pi = (size_t)(blockIdx.x * 64u + lane) * (RMD_PATH_STRIDE) + path_len;
+				size_t pi = (size_t)list_idx * (RMD_PATH_STRIDE) + path_len;
 				path_obj[pi] = oi;
 				path_sub[pi] = oi >= 0 ? sub : 0u;
 				path_len++;
@@ -123,7 +183,7 @@ __global__ __launch_bounds__(64) void render_kernel(RenderParams P, const DevObj
 					terminal = true;
 				} else {
 					V3 normal;
-					if (o.geometry_kind == 0u) normal = ld3(o.normal);                                // plane.rs:28-32
+					if (o.geometry_kind == 0u) normal = ld3(o.normal);                        // plane.rs:28-32
 					else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin)); // sphere.rs:31-35
 					else {
 						const DevGrid &g = grids[o.grid_index];
@@ -135,23 +195,27 @@ __global__ __launch_bounds__(64) void render_kernel(RenderParams P, const DevObj
 					stack[stack_slot(lvl, 1, lane)] = b.A.y;
 					stack[stack_slot(lvl, 2, lane)] = b.A.z;
 					stack[stack_slot(lvl, 3, lane)] = b.cosv;
-					stack[stack_slot(lvl, 4, lane)] = b.d1;
-					stack[stack_slot(lvl, 5, lane)] = b.d2;
-					specmask = b.specular ? (specmask | (1u << lvl)) : (specmask & ~(1u << lvl));
+					stack[stack_slot(lvl, 4, lane)] = b.specular ? b.d2 : b.d1;
+					const uint32_t bit = 1u << lvl;
+					specmask = b.specular ? (specmask | bit) : (specmask & ~bit);
+					metalmask = o.material_kind == 1u ? (metalmask | bit) : (metalmask & ~bit);
 					ro = b.next_origin, rd = b.next_dir;
 					depth++;
 					if (depth > P.bounce_limit) terminal = true; // :235-237: the recursive call returns 0 at once
 				}
 			}
 		}
-		if (terminal) {
+		if (alive && terminal) {
 			// unwind the recursion: levels depth-2 .. 0, each applying its bounce's return expression
+			//   diffuse  (:281-282)  ((A (.) L) * cos) / (prob_d * pdf)
+			//   specular (:315-318)  (((A (.) L) * cos) / (1 - prob_d)) / pdf      1 - prob_d = 1.0 (Metal) or 0.5 (Diffuse)
 			for (int lvl = (int)depth - 2; lvl >= 0; lvl--) {
 				V3 A = mk(stack[stack_slot(lvl, 0, lane)], stack[stack_slot(lvl, 1, lane)], stack[stack_slot(lvl, 2, lane)]);
 				double cosv = stack[stack_slot(lvl, 3, lane)];
-				double d1 = stack[stack_slot(lvl, 4, lane)];
-				L = (hadamard(A, L) * cosv) / d1;
-				if (specmask & (1u << lvl)) L = L / stack[stack_slot(lvl, 5, lane)];
+				double d = stack[stack_slot(lvl, 4, lane)];
+				L = hadamard(A, L) * cosv;
+				if (specmask & (1u << lvl)) L = L / ((metalmask & (1u << lvl)) ? 1.0 : 0.5);
+				L = L / d;
 			}
 			acc = acc + L; // src/trace.rs:203
 			s++;
@@ -267,47 +331,93 @@ __global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const dou
 	}
 }
 
-// mode 0: Scene::intersect -> (obj, t, sub);  mode 1: AccGrid::intersects on grid `g` -> (hit, t, tri)
+// mode 0: Scene::intersect -> (obj, t, sub);  mode 1: AccGrid::intersects on grid `g` -> (hit, t, tri).
+// 64-thread workgroups; the grids' occupancy masks are read from LDS exactly as in the render kernel when `use_masks`.
 __global__ __launch_bounds__(64) void probe_scene_kernel(int mode, uint32_t g, uint32_t n, const DevObject *__restrict__ objs,
-                                                         uint32_t n_objects, const DevGrid *__restrict__ grids,
-                                                         const double *__restrict__ rays, double *__restrict__ out) {
+                                                         uint32_t n_objects, const DevGrid *__restrict__ grids, uint32_t n_grids,
+                                                         uint32_t mask_words_total, const double *__restrict__ rays,
+                                                         double *__restrict__ out) {
+	extern __shared__ __align__(16) unsigned char smem[];
+	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem);
+	for (uint32_t gi = 0; gi < n_grids && mask_words_total; gi++) {
+		const DevGrid &gg = grids[gi];
+		if (gg.mask_lds_word == 0xFFFFFFFFu) continue;
+		for (uint32_t i = threadIdx.x; i < gg.mask_n_words; i += 64u) lmasks[gg.mask_lds_word + i] = gg.mask_words[i];
+	}
+	__syncthreads();
+	const uint32_t *lds_masks = mask_words_total ? lmasks : nullptr;
+	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(smem + (size_t)((mask_words_total + 3u) & ~3u) * 4u);
 	uint32_t i = blockIdx.x * 64u + threadIdx.x;
-	if (i >= n) return;
-	V3 ro = ld3(rays + (size_t)i * 6), rd = ld3(rays + (size_t)i * 6 + 3);
-	double *o = out + (size_t)i * 3;
+	const bool want = i < n;
+	const size_t ri = want ? i : 0;
+	V3 ro = ld3(rays + ri * 6), rd = ld3(rays + ri * 6 + 3);
+	double o0, o1, o2;
 	if (mode == 0) {
 		double t;
 		uint32_t sub;
-		int oi = scene_intersect(objs, n_objects, grids, ro, rd, t, sub);
-		o[0] = oi, o[1] = oi >= 0 ? t : 0.0, o[2] = oi >= 0 ? sub : 0u;
+		int oi = scene_intersect_wave(objs, n_objects, grids, lds_masks, scr, want, ro, rd, t, sub);
+		o0 = oi, o1 = oi >= 0 ? t : 0.0, o2 = oi >= 0 ? sub : 0u;
 	} else {
 		double t = 0.0;
 		uint32_t tri = 0;
-		bool h = grid_intersect(grids[g], ro, rd, t, tri);
-		o[0] = h, o[1] = h ? t : 0.0, o[2] = h ? tri : 0u;
+		bool h = false;
+		const DevGrid &gg = grids[g];
+		const uint32_t *mask = (lds_masks && gg.mask_lds_word != 0xFFFFFFFFu) ? lds_masks + gg.mask_lds_word : nullptr;
+		grid_intersect_wave(gg, mask, scr, want, ro, rd, h, t, tri);
+		o0 = h, o1 = h ? t : 0.0, o2 = h ? tri : 0u;
+	}
+	if (want) {
+		double *o = out + (size_t)i * 3;
+		o[0] = o0, o[1] = o1, o[2] = o2;
 	}
 }
 
 // ---------------------------------------------------------------- launchers
-size_t render_lds_bytes(uint32_t n_objects, uint32_t bounce_limit) {
-	return (size_t)n_objects * sizeof(DevObject) + (size_t)bounce_limit * 6u * 64u * sizeof(double);
+size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit, uint32_t waves_per_wg) {
+	// a scene has grids exactly when it has mask words reserved (an all-empty grid still reserves 4)
+	return (size_t)n_objects * sizeof(DevObject) + (size_t)((mask_words_total + 3u) & ~3u) * 4u +
+	       (size_t)waves_per_wg * wave_lds_bytes(bounce_limit, mask_words_total ? 1u : 0u);
+}
+
+// Waves per workgroup: one for grid-less scenes (finest load balance); with grids, as many waves as fit the CU's
+// 160 KiB of LDS beside the shared occupancy masks, up to 8 (2 per SIMD at this kernel's register budget).
+uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit) {
+	if (mask_words_total == 0) return 1;
+	uint32_t w = 8;
+	while (w > 1 && render_lds_bytes(n_objects, mask_words_total, bounce_limit, w) > kLdsBudgetBytes) w--;
+	return w;
 }
 
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                                const WaveTile *wave_tiles, double *accum) {
 	if (P.n_work == 0) return hipSuccess;
-	size_t lds = render_lds_bytes(P.n_objects, P.bounce_limit);
-	hipLaunchKernelGGL(render_kernel<false>, dim3(P.n_work), dim3(64), lds, stream, P, objs, grids, (const void *)wave_tiles, accum,
-	                   (int32_t *)nullptr, (uint32_t *)nullptr);
+	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total, P.bounce_limit);
+	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, P.bounce_limit, wpw);
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(render_kernel<false>, dim3((P.n_work + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids,
+	                   (const void *)wave_tiles, accum, (int32_t *)nullptr, (uint32_t *)nullptr);
 	return hipGetLastError();
 }
 
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub) {
 	if (P.n_work == 0) return hipSuccess;
-	size_t lds = render_lds_bytes(P.n_objects, P.bounce_limit);
-	hipLaunchKernelGGL(render_kernel<true>, dim3((P.n_work + 63u) / 64u), dim3(64), lds, stream, P, objs, grids, (const void *)list,
-	                   rgb_out, path_obj, path_sub);
+	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total, P.bounce_limit);
+	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, P.bounce_limit, wpw);
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	const uint32_t n_waves = (P.n_work + 63u) / 64u;
+	hipLaunchKernelGGL(render_kernel<true>, dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids,
+	                   (const void *)list, rgb_out, path_obj, path_sub);
 	return hipGetLastError();
 }
 
@@ -328,9 +438,16 @@ hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in
 }
 
 hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,
-                              const DevGrid *grids, const double *rays, double *out) {
+                              const DevGrid *grids, uint32_t n_grids, uint32_t mask_words_total, const double *rays, double *out) {
 	if (n == 0) return hipSuccess;
-	hipLaunchKernelGGL(probe_scene_kernel, dim3((n + 63u) / 64u), dim3(64), 0, stream, mode, g, n, objs, n_objects, grids, rays, out);
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_scene_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(probe_scene_kernel, dim3((n + 63u) / 64u), dim3(64), (size_t)((mask_words_total + 3u) & ~3u) * 4u + sizeof(WalkScratch), stream, mode, g, n, objs,
+	                   n_objects, grids, n_grids, mask_words_total, rays, out);
 	return hipGetLastError();
 }
 

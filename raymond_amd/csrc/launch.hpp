@@ -30,7 +30,12 @@ enum ProbeOp {
 	PROBE_OP_COUNT
 };
 
-size_t render_lds_bytes(uint32_t n_objects, uint32_t bounce_limit);
+// LDS a workgroup may use: the CU's 160 KiB less a margin for alignment
+constexpr size_t kLdsBudgetBytes = 160u * 1024u;
+// LDS bytes reserved for the grids' occupancy masks (shared by the waves of a workgroup)
+constexpr size_t kMaskBudgetBytes = 48u * 1024u;
+size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit, uint32_t waves_per_wg);
+uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit);
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                                const WaveTile *wave_tiles, double *accum);
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
@@ -40,6 +45,6 @@ hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8
 hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in, int in_stride, double *out, int out_stride,
                         const RenderParams &P);
 hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,
-                              const DevGrid *grids, const double *rays, double *out);
+                              const DevGrid *grids, uint32_t n_grids, uint32_t mask_words_total, const double *rays, double *out);
 
 } // namespace rmd
