@@ -3,6 +3,7 @@
 #define RMD_WITH_HIP 1
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -140,6 +141,7 @@ RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rm
 	P.mask_words_total = scene ? scene->mask_words_total : 0;
 	P.key0 = (uint32_t)st->seed, P.key1 = (uint32_t)(st->seed >> 32);
 	P.use_dof = cam->aperture_radius > 0.0 ? 1u : 0u;
+	if (const char *dbg = std::getenv("RMD_DEBUG")) P.debug_flags = (uint32_t)std::atoi(dbg); // timing-only ablations; results are wrong
 	return P;
 }
 
@@ -237,6 +239,11 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 			d.res[a] = g.resolution[a];
 		}
 		d.n_cells = g.n_cells, d.n_tris = g.n_tris;
+		// the kernel keeps the reference's linear cell index x + res.x*(y + z*res.z) in 32 bits
+		if ((uint64_t)g.resolution[0] * ((uint64_t)g.resolution[1] + (uint64_t)g.resolution[2] * g.resolution[2]) >= (1ull << 31)) {
+			rmd_scene_destroy(sc);
+			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: grid resolution too large for 31-bit cell indices");
+		}
 		// cell entries + contiguous per-cell triangle runs (device_types.hpp): record = v0, edge1 = v1 - v0, edge2 = v2 - v0
 		// (triangle.rs:16-17, same subtraction, done once), triangle index, pad — in mapping_table order
 		const uint64_t n_refs = g.n_mapping - g.n_cells;
@@ -353,10 +360,27 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	if (rmd_status s = prepare_wave_tiles(ctx, camera, tiles, n_tiles)) return s;
 	rmd::RenderParams P = rmd::make_params(scene, camera, settings);
 	P.n_work = ctx->n_wave_tiles;
+	static unsigned long long *dbg_counters = nullptr;
+	if (P.debug_flags & 24u) {
+		if (!dbg_counters) RMD_HIP(ctx, hipMalloc((void **)&dbg_counters, 16 * sizeof(unsigned long long)));
+		RMD_HIP(ctx, hipMemsetAsync(dbg_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+		P.debug_counters = dbg_counters;
+	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
 	RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, P, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev));
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
 	ctx->timed = true;
+	if (P.debug_flags & 24u) {
+		unsigned long long h[16];
+		RMD_HIP(ctx, hipMemcpyAsync(h, dbg_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+		RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (P.debug_flags & 16u)
+			std::fprintf(stderr, "[rmd stamps, cycles] init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
+			             h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
+		else
+		std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu pairs=%llu tests=%llu chunks=%llu\n",
+		             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+	}
 	return RMD_OK;
 }
 

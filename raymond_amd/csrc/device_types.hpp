@@ -78,6 +78,8 @@ struct RenderParams {
 	uint32_t use_dof;
 	uint32_t n_grids;
 	uint32_t mask_words_total; // LDS words reserved for the grids' occupancy masks
+	uint32_t debug_flags;      // diagnostics (RMD_DEBUG env): 1 = skip triangle tests, 2 = skip grid walks (timing only, wrong results), 8 = count walk events
+	unsigned long long *debug_counters; // 16 counters, only touched when debug_flags & 8
 };
 
 // List mode (probe): one lane per explicit (x, y, sample).

@@ -17,6 +17,10 @@
 #pragma once
 #include "device_core.hpp"
 
+#ifndef RMD_DIAG
+#define RMD_DIAG 0 // 1: compile the walk's event counters / s_memtime stamps (RMD_DEBUG=8 / 16); never in the shipped build
+#endif
+
 namespace rmd {
 
 RMD_DEV double readlane_f64(double v, int lane) {
@@ -40,31 +44,30 @@ RMD_DEV TriRecord load_record(const unsigned char *p) {
 	return r;
 }
 
-// One DDA step (acc_grid.rs:155-183).  Returns false when the ray leaves the grid.
-RMD_DEV bool dda_step(int32_t &cx, int32_t &cy, int32_t &cz, double &tmx, double &tmy, double &tmz, int32_t sx, int32_t sy, int32_t sz,
-                      double tdx, double tdy, double tdz, int32_t rx, int32_t ry, int32_t rz) {
-	if (tmx < tmy) {
-		if (tmx < tmz) {
-			cx += sx;
-			if (cx >= rx || cx < 0) return false;
-			tmx += tdx;
-		} else {
-			cz += sz;
-			if (cz >= rz || cz < 0) return false;
-			tmz += tdz;
-		}
-	} else {
-		if (tmy < tmz) {
-			cy += sy;
-			if (cy >= ry || cy < 0) return false;
-			tmy += tdy;
-		} else {
-			cz += sz;
-			if (cz >= rz || cz < 0) return false;
-			tmz += tdz;
-		}
-	}
-	return true;
+// One DDA step (acc_grid.rs:155-183), branch-free: the same three comparisons select the axis
+// (x if tmx<tmy && tmx<tmz; y if !(tmx<tmy) && tmy<tmz; else z), the cell moves, and that axis' t_max advances
+// (its value is irrelevant once the ray has left the grid).  `idx` is the reference's linear cell index
+// x + res.x*(y + z*res.z) (Q5: res.z where res.y is meant) kept incrementally: a step along x/y/z adds dix/diy/diz.
+// 32-bit arithmetic is exact because the upload rejects grids whose largest reachable index does not fit 31 bits.
+// Outputs the stepped state in n*; returns false when the ray leaves the grid (:158,:164,:172,:178).
+RMD_DEV bool dda_step(int32_t cx, int32_t cy, int32_t cz, uint32_t idx, double tmx, double tmy, double tmz, int32_t sx, int32_t sy,
+                      int32_t sz, int32_t dix, int32_t diy, int32_t diz, double tdx, double tdy, double tdz, int32_t rx, int32_t ry,
+                      int32_t rz, int32_t &ncx, int32_t &ncy, int32_t &ncz, uint32_t &nidx, double &ntmx, double &ntmy, double &ntmz) {
+	const bool lt_xy = tmx < tmy, lt_xz = tmx < tmz, lt_yz = tmy < tmz;
+	const bool ax = lt_xy && lt_xz;
+	const bool ay = !lt_xy && lt_yz;
+	const bool az = !ax && !ay;
+	const int32_t c_new = ax ? cx + sx : (ay ? cy + sy : cz + sz);
+	const int32_t r_sel = ax ? rx : (ay ? ry : rz);
+	ncx = ax ? c_new : cx;
+	ncy = ay ? c_new : cy;
+	ncz = az ? c_new : cz;
+	nidx = idx + (uint32_t)(ax ? dix : (ay ? diy : diz));
+	const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+	ntmx = ax ? nx : tmx;
+	ntmy = ay ? ny : tmy;
+	ntmz = az ? nz : tmz;
+	return (uint32_t)c_new < (uint32_t)r_sel; // 0 <= c_new < res
 }
 
 // Per-wave LDS scratch of the cooperative triangle tests (3.75 KiB).
@@ -79,18 +82,33 @@ struct WalkScratch {
 // lds_mask: occupancy bits of this grid in LDS (bit i covers cells [i << shift, (i+1) << shift)), or nullptr.
 // scr: this wave's scratch in LDS.
 RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, WalkScratch &scr, bool want, V3 ro, V3 rd, bool &hit_out,
-                                 double &t_out, uint32_t &tri_out) {
+                                 double &t_out, uint32_t &tri_out, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
 	const uint64_t resx = g.res[0], resz = g.res[2], n_cells = g.n_cells;
 	const uint32_t mask_bits = g.mask_bits, mask_shift = g.mask_shift;
 	const CellEntry *__restrict__ entries = g.cell_entries;
 	const unsigned char *__restrict__ runs = reinterpret_cast<const unsigned char *>(g.tri_runs);
+#if RMD_DIAG
+	const bool stamp = (debug_flags & 16u) && dbg;
+	unsigned long long t_prev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+	unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph5 = 0, ph6 = 0, ph7 = 0;
+#define RMD_STAMP(n)                                         \
+	if (stamp) {                                             \
+		__builtin_amdgcn_s_waitcnt(0);                       \
+		unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+		ph##n += now_ - t_prev;                               \
+		t_prev = now_;                                       \
+	}
+#else
+#define RMD_STAMP(n)
+#endif
 
 	bool walking = false;
-	int32_t cx = 0, cy = 0, cz = 0, sx = 1, sy = 1, sz = 1;
-	double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
-	if (want) {
+	int32_t cx = 0, cy = 0, cz = 0, sx = 1, sy = 1, sz = 1, dix = 0, diy = 0, diz = 0;
+	uint32_t idx = 0;
+	double tmx = 0.0, tmy = 0.0, tmz = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
+	if (want && !(debug_flags & 2u)) {
 		// acc_grid.rs:90-125
 		V3 bmin = ld3(g.bbox_min);
 		double t_outer;
@@ -105,7 +123,14 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			}
 			ok = ok && !(rd.x != rd.x || rd.y != rd.y || rd.z != rd.z); // signum(NaN).cast::<i32>() panics: miss
 			if (ok) {
+				// first cell (:128-131): `as usize` sign-extends and the index arithmetic wraps (release build)
+				const uint64_t idx0 = (uint64_t)(int64_t)cx + resx * ((uint64_t)(int64_t)cy + (uint64_t)(int64_t)cz * resz);
+				ok = idx0 < n_cells; // else None
+				idx = (uint32_t)idx0;
+			}
+			if (ok) {
 				sx = signbit(rd.x) ? -1 : 1, sy = signbit(rd.y) ? -1 : 1, sz = signbit(rd.z) ? -1 : 1;
+				dix = sx, diy = sy * (int32_t)resx, diz = sz * (int32_t)(resx * resz);
 				tdx = (rd.x < 0.0 ? -cs.x : cs.x) / rd.x;
 				tdy = (rd.y < 0.0 ? -cs.y : cs.y) / rd.y;
 				tdz = (rd.z < 0.0 ? -cs.z : cs.z) / rd.z;
@@ -120,25 +145,40 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	bool found = false;
 	double found_t = 0.0;
 	uint32_t found_tri = 0;
+	RMD_STAMP(0)
 
+#if RMD_DIAG
+	const bool count_events = (debug_flags & 8u) && dbg;
+#else
+	constexpr bool count_events = false;
+#endif
+	if (count_events && lane == 0) atomicAdd(&dbg[0], 1ull), atomicAdd(&dbg[1], (unsigned long long)__popcll(__ballot(walking)) * 0ull);
+	if (count_events) { unsigned long long wm = __ballot(walking); if (lane == 0) { atomicAdd(&dbg[1], (unsigned long long)__popcll(wm)); if (wm) atomicAdd(&dbg[2], 1ull); } }
 	for (;;) {
-		// 1. per lane: advance to the next cell that may hold triangles (ALU + LDS only)
-		uint64_t idx = 0;
+		// 1. per lane: advance to the next cell that may hold triangles (ALU + LDS only).  Every cell the lane stands on
+		//    has a valid index (< n_cells, checked for the first cell above and after every step below, :129-131).
+		//    The next step is computed while the mask word of the current cell is still in flight.
+		if (count_events && lane == 0) atomicAdd(&dbg[3], 1ull);
 		while (walking) {
-			// `as usize` sign-extends and the index arithmetic wraps (release build); Q5: res.z where res.y is meant
-			idx = (uint64_t)(int64_t)cx + resx * ((uint64_t)(int64_t)cy + (uint64_t)(int64_t)cz * resz);
-			if (idx >= n_cells) { // :129-131 -> None
-				walking = false;
-				break;
-			}
+			if (count_events) { unsigned long long am = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(am)) { atomicAdd(&dbg[4], 1ull); atomicAdd(&dbg[5], (unsigned long long)__popcll(am)); } }
 			bool candidate = true;
+			uint32_t word = 0xFFFFFFFFu;
+			const uint32_t bit = idx >> mask_shift;
 			if (lds_mask) {
-				uint32_t bit = (uint32_t)(idx >> mask_shift);
-				candidate = bit < mask_bits && ((lds_mask[bit >> 5] >> (bit & 31u)) & 1u);
+				candidate = bit < mask_bits;
+				word = lds_mask[candidate ? (bit >> 5) : 0u];
 			}
+			int32_t ncx, ncy, ncz;
+			uint32_t nidx;
+			double ntmx, ntmy, ntmz;
+			bool inside = dda_step(cx, cy, cz, idx, tmx, tmy, tmz, sx, sy, sz, dix, diy, diz, tdx, tdy, tdz, rx, ry, rz, ncx, ncy, ncz, nidx, ntmx, ntmy, ntmz);
+			inside = inside && nidx < (uint32_t)n_cells; // next cell past the cell array: the walk returns None there
+			candidate = candidate && ((word >> (bit & 31u)) & 1u);
 			if (candidate) break;
-			if (!dda_step(cx, cy, cz, tmx, tmy, tmz, sx, sy, sz, tdx, tdy, tdz, rx, ry, rz)) walking = false;
+			cx = ncx, cy = ncy, cz = ncz, idx = nidx, tmx = ntmx, tmy = ntmy, tmz = ntmz;
+			walking = inside;
 		}
+		RMD_STAMP(1)
 		if (__ballot(walking) == 0ull) break;
 
 		// 2. candidate cells: {first record, count} in one 8-byte gather per lane
@@ -155,7 +195,8 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		//    lanes read neighbouring 80-byte records: coalesced).  Hits are rare; they are applied by a scalar loop over
 		//    the hit ballot in ascending lane order = ascending (pair, triangle) order with a strict '<', which is the
 		//    reference's sequential scan of the cell (acc_grid.rs:135-149: closest starts at 5712515.0, first wins ties).
-		const bool pending = walking && count > 0u;
+		RMD_STAMP(2)
+		const bool pending = walking && count > 0u && !(debug_flags & 1u);
 		const unsigned long long pmask = __ballot(pending);
 		if (pmask != 0ull) {
 			const uint32_t n_pairs = (uint32_t)__popcll(pmask);
@@ -168,6 +209,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				if ((int)lane >= d) incl += up;
 			}
 			const uint32_t total = readlane_u32(incl, 63);
+			if (count_events && lane == 0) atomicAdd(&dbg[6], 1ull), atomicAdd(&dbg[7], (unsigned long long)n_pairs), atomicAdd(&dbg[8], (unsigned long long)total), atomicAdd(&dbg[9], (unsigned long long)((total + 63u) / 64u));
 			if (pending) {
 				scr.start[rank] = incl - count;
 				scr.first[rank] = first;
@@ -178,6 +220,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			RMD_STAMP(3)
 			double closest = 5712515.0;
 			uint32_t closest_tri = 0;
 			bool any = false;
@@ -201,6 +244,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 					tri = r.tri;
 					h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t);
 				}
+				RMD_STAMP(5)
 				unsigned long long hits = __ballot(h);
 				while (hits) {
 					const int l = (int)__builtin_ctzll(hits);
@@ -215,6 +259,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 					}
 				}
 			}
+			RMD_STAMP(6)
 			__builtin_amdgcn_wave_barrier(); // the scratch is rewritten next round
 			if (any) {                       // :151-153 first cell with any hit wins
 				found = true;
@@ -226,9 +271,18 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 
 		// 4. lanes whose cell yielded nothing move on
 		if (walking) {
-			if (!dda_step(cx, cy, cz, tmx, tmy, tmz, sx, sy, sz, tdx, tdy, tdz, rx, ry, rz)) walking = false;
+			const bool inside = dda_step(cx, cy, cz, idx, tmx, tmy, tmz, sx, sy, sz, dix, diy, diz, tdx, tdy, tdz, rx, ry, rz, cx, cy, cz, idx, tmx, tmy, tmz);
+			walking = inside && idx < (uint32_t)n_cells;
 		}
 	}
+	RMD_STAMP(7)
+#if RMD_DIAG
+	if (stamp && lane == 0) {
+		atomicAdd(&dbg[8], ph0), atomicAdd(&dbg[9], ph1), atomicAdd(&dbg[10], ph2), atomicAdd(&dbg[11], ph3);
+		atomicAdd(&dbg[13], ph5), atomicAdd(&dbg[14], ph6), atomicAdd(&dbg[15], ph7);
+	}
+#endif
+#undef RMD_STAMP
 	hit_out = found;
 	t_out = found_t;
 	tri_out = found_tri;

@@ -44,7 +44,8 @@ RMD_DEV uint32_t work_item_of_block(uint32_t b, uint32_t nb) {
 // table is indexed uniformly (scalar loads); planes and spheres are tested per lane, a grid object runs the
 // wave-cooperative walk.
 RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids,
-                                 const uint32_t *lds_masks, WalkScratch &scr, bool want, V3 ro, V3 rd, double &t_best, uint32_t &sub_best) {
+                                 const uint32_t *lds_masks, WalkScratch &scr, bool want, V3 ro, V3 rd, double &t_best, uint32_t &sub_best,
+                                 uint32_t debug_flags = 0, unsigned long long *dbg = nullptr) {
 	double closest = kFMax;
 	int best = -1;
 	uint32_t sub = 0;
@@ -60,7 +61,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 		} else {
 			const DevGrid &g = grids[o.grid_index];
 			const uint32_t *mask = (lds_masks && g.mask_lds_word != 0xFFFFFFFFu) ? lds_masks + g.mask_lds_word : nullptr;
-			grid_intersect_wave(g, mask, scr, want, ro, rd, hit, t, tri);
+			grid_intersect_wave(g, mask, scr, want, ro, rd, hit, t, tri, debug_flags, dbg);
 		}
 		if (want && hit) {
 			if (t < closest) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevOb
 		// src/trace.rs:239
 		double t;
 		uint32_t sub;
-		const int oi = scene_intersect_wave(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub);
+		const int oi = scene_intersect_wave(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
 		if (want) {
 			if (LIST && path_obj) {
 				size_t pi = (size_t)list_idx * (RMD_PATH_STRIDE) + path_len;
