@@ -106,8 +106,8 @@ rmd_status check_render_args(rmd_context *ctx, const rmd_scene *scene, const rmd
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: backbuffer size must be 1..65535 per axis");
 	if (st->bounce_limit > RMD_MAX_BOUNCE_LIMIT) return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: bounce_limit above RMD_MAX_BOUNCE_LIMIT");
 	if ((uint64_t)st->sample_begin + st->sample_count > 0xFFFFFFFFull) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: sample range overflows u32");
-	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, st->bounce_limit, 1) > rmd::kLdsBudgetBytes)
-		return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: object table + bounce stack exceed the 160 KiB LDS of a CU");
+	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, 1) > rmd::kLdsBudgetBytes)
+		return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: object table + grid masks exceed the 160 KiB LDS of a CU");
 	return RMD_OK;
 }
 

@@ -20,14 +20,8 @@
 
 namespace rmd {
 
-// LDS stack slot (level, comp, lane), 5 doubles per level (A.xyz, cos, d): consecutive lanes hit consecutive 8-byte
-// words, so every access is bank-conflict free whatever level each lane is at (levels differ by multiples of 512 B).
-constexpr uint32_t kStackDoublesPerLevel = 5;
-// LDS per wave: [WalkScratch if the scene has grids][bounce stack]
-__host__ __device__ inline size_t wave_lds_bytes(uint32_t bounce_limit, uint32_t n_grids) {
-	return (n_grids ? sizeof(WalkScratch) : 0) + (size_t)bounce_limit * kStackDoublesPerLevel * 64u * sizeof(double);
-}
-RMD_DEV int stack_slot(uint32_t level, int comp, uint32_t lane) { return (int)((level * kStackDoublesPerLevel + (uint32_t)comp) * 64u + lane); }
+// LDS per wave: the cooperative-walk scratch, only when the scene has grids.
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) : 0; }
 
 // Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
 // reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
@@ -43,6 +37,7 @@ RMD_DEV uint32_t work_item_of_block(uint32_t b, uint32_t nb) {
 // Wave-level: called by all 64 lanes in uniform control flow, `want` marks the lanes that carry a ray.  The object
 // table is indexed uniformly (scalar loads); planes and spheres are tested per lane, a grid object runs the
 // wave-cooperative walk.
+template <bool GRID>
 RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids,
                                  const uint32_t *lds_masks, WalkScratch &scr, bool want, V3 ro, V3 rd, double &t_best, uint32_t &sub_best,
                                  uint32_t debug_flags = 0, unsigned long long *dbg = nullptr) {
@@ -58,7 +53,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
 		} else if (o.geometry_kind == 1u) {
 			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
-		} else {
+		} else if constexpr (GRID) {
 			const DevGrid &g = grids[o.grid_index];
 			const uint32_t *mask = (lds_masks && g.mask_lds_word != 0xFFFFFFFFu) ? lds_masks + g.mask_lds_word : nullptr;
 			grid_intersect_wave(g, mask, scr, want, ro, rd, hit, t, tri, debug_flags, dbg);
@@ -76,8 +71,8 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	return best;
 }
 
-template <bool LIST>
-__global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
+template <bool LIST, bool GRID>
+__global__ __launch_bounds__(GRID ? 512 : 64) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
                                                      const DevGrid *__restrict__ grids, const void *__restrict__ work,
                                                      double *__restrict__ out, int32_t *__restrict__ path_obj,
                                                      uint32_t *__restrict__ path_sub) {
@@ -87,9 +82,8 @@ __global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevOb
 	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
 	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
-	                          (size_t)wave * wave_lds_bytes(P.bounce_limit, P.n_grids);
+	                          (size_t)wave * wave_lds_bytes(P.n_grids);
 	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
-	double *stack = reinterpret_cast<double *>(wave_lds + (P.n_grids ? sizeof(WalkScratch) : 0));
 
 	// stage the object table and the occupancy masks: coalesced, once per workgroup
 	{
@@ -135,9 +129,8 @@ __global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevOb
 	Rng rng;
 	rng.init(P.key0, P.key1, pixel, s);
 	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
-	uint32_t depth = 1;     // depth argument of the trace() call being evaluated
-	uint32_t specmask = 0;  // bit l: stack level l is a specular bounce
-	uint32_t metalmask = 0; // bit l: stack level l hit a Metal material (1 - prob_d = 1.0, else 0.5)
+	uint32_t depth = 1; // depth argument of the trace() call being evaluated
+	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
 	uint32_t path_len = 0;
 	bool fresh = true;
 
@@ -157,7 +150,7 @@ __global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevOb
 				primary_ray(P, x, y, u0, u1, ro, rd);
 			}
 			depth = 1;
-			specmask = 0, metalmask = 0;
+			T = mk(1.0, 1.0, 1.0);
 			fresh = false;
 			if (!ok) terminal = true;                  // reference panics here; the sample contributes zero
 			if (P.bounce_limit == 0u) terminal = true; // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237)
@@ -166,7 +159,7 @@ __global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevOb
 		// src/trace.rs:239
 		double t;
 		uint32_t sub;
-		const int oi = scene_intersect_wave(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
+		const int oi = scene_intersect_wave<GRID>(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
 		if (want) {
 			if (LIST && path_obj) {
 				size_t pi = (size_t)list_idx * (RMD_PATH_STRIDE) + path_len;
@@ -186,20 +179,21 @@ __global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevOb
 					V3 normal;
 					if (o.geometry_kind == 0u) normal = ld3(o.normal);                        // plane.rs:28-32
 					else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin)); // sphere.rs:31-35
-					else {
+					else if constexpr (GRID) {
 						const DevGrid &g = grids[o.grid_index];
 						normal = triangle_normal(g.tri_pos + (size_t)sub * 9, g.tri_nrm + (size_t)sub * 9, frag); // acc_grid.rs:85-87
+					} else {
+						normal = mk(0.0, 0.0, 0.0); // unreachable: a scene with grid objects runs the GRID instantiation
 					}
 					Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
-					const uint32_t lvl = depth - 1u;
-					stack[stack_slot(lvl, 0, lane)] = b.A.x;
-					stack[stack_slot(lvl, 1, lane)] = b.A.y;
-					stack[stack_slot(lvl, 2, lane)] = b.A.z;
-					stack[stack_slot(lvl, 3, lane)] = b.cosv;
-					stack[stack_slot(lvl, 4, lane)] = b.specular ? b.d2 : b.d1;
-					const uint32_t bit = 1u << lvl;
-					specmask = b.specular ? (specmask | bit) : (specmask & ~bit);
-					metalmask = o.material_kind == 1u ? (metalmask | bit) : (metalmask & ~bit);
+					// trace() returns  diffuse (:281-282)  ((A (.) radiance) * cos) / (prob_d * pdf)
+					//                  specular (:315-318) (((A (.) radiance) * cos) / (1 - prob_d)) / pdf
+					// i.e. radiance times a per-channel weight known before the recursive call.  The weights are multiplied
+					// forward into T instead of being applied on the way back up (same factors, different association:
+					// a few ulp per bounce, far inside the 1e-9 per-sample bar).
+					V3 wgt = (b.A * b.cosv) / b.d1;
+					if (b.specular) wgt = wgt / b.d2;
+					T = hadamard(T, wgt);
 					ro = b.next_origin, rd = b.next_dir;
 					depth++;
 					if (depth > P.bounce_limit) terminal = true; // :235-237: the recursive call returns 0 at once
@@ -207,17 +201,7 @@ __global__ __launch_bounds__(512) void render_kernel(RenderParams P, const DevOb
 			}
 		}
 		if (alive && terminal) {
-			// unwind the recursion: levels depth-2 .. 0, each applying its bounce's return expression
-			//   diffuse  (:281-282)  ((A (.) L) * cos) / (prob_d * pdf)
-			//   specular (:315-318)  (((A (.) L) * cos) / (1 - prob_d)) / pdf      1 - prob_d = 1.0 (Metal) or 0.5 (Diffuse)
-			for (int lvl = (int)depth - 2; lvl >= 0; lvl--) {
-				V3 A = mk(stack[stack_slot(lvl, 0, lane)], stack[stack_slot(lvl, 1, lane)], stack[stack_slot(lvl, 2, lane)]);
-				double cosv = stack[stack_slot(lvl, 3, lane)];
-				double d = stack[stack_slot(lvl, 4, lane)];
-				L = hadamard(A, L) * cosv;
-				if (specmask & (1u << lvl)) L = L / ((metalmask & (1u << lvl)) ? 1.0 : 0.5);
-				L = L / d;
-			}
+			L = hadamard(T, L);
 			acc = acc + L; // src/trace.rs:203
 			s++;
 			fresh = true;
@@ -356,7 +340,7 @@ __global__ __launch_bounds__(64) void probe_scene_kernel(int mode, uint32_t g, u
 	if (mode == 0) {
 		double t;
 		uint32_t sub;
-		int oi = scene_intersect_wave(objs, n_objects, grids, lds_masks, scr, want, ro, rd, t, sub);
+		int oi = scene_intersect_wave<true>(objs, n_objects, grids, lds_masks, scr, want, ro, rd, t, sub);
 		o0 = oi, o1 = oi >= 0 ? t : 0.0, o2 = oi >= 0 ? sub : 0u;
 	} else {
 		double t = 0.0;
@@ -374,52 +358,51 @@ __global__ __launch_bounds__(64) void probe_scene_kernel(int mode, uint32_t g, u
 }
 
 // ---------------------------------------------------------------- launchers
-size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit, uint32_t waves_per_wg) {
-	// a scene has grids exactly when it has mask words reserved (an all-empty grid still reserves 4)
+size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg) {
+	// a scene has grids exactly when it has mask words reserved (an all-empty grid still reserves some)
 	return (size_t)n_objects * sizeof(DevObject) + (size_t)((mask_words_total + 3u) & ~3u) * 4u +
-	       (size_t)waves_per_wg * wave_lds_bytes(bounce_limit, mask_words_total ? 1u : 0u);
+	       (size_t)waves_per_wg * wave_lds_bytes(mask_words_total ? 1u : 0u);
 }
 
-// Waves per workgroup: one for grid-less scenes (finest load balance); with grids, as many waves as fit the CU's
-// 160 KiB of LDS beside the shared occupancy masks, up to 8 (2 per SIMD at this kernel's register budget).
-uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit) {
+// Waves per workgroup: one for grid-less scenes (finest load balance); with grids the waves of a workgroup share the
+// occupancy masks staged in LDS.
+uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total) {
 	if (mask_words_total == 0) return 1;
-	uint32_t w = 8;
-	while (w > 1 && render_lds_bytes(n_objects, mask_words_total, bounce_limit, w) > kLdsBudgetBytes) w--;
+	uint32_t w = kGridWavesPerWg;
+	while (w > 1 && render_lds_bytes(n_objects, mask_words_total, w) > kLdsBudgetBytes) w--;
 	return w;
+}
+
+template <bool LIST, bool GRID>
+static hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
+                                uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub) {
+	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total);
+	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, wpw);
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<LIST, GRID>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                   (int)kLdsBudgetBytes);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL((render_kernel<LIST, GRID>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
+	                   path_obj, path_sub);
+	return hipGetLastError();
 }
 
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                                const WaveTile *wave_tiles, double *accum) {
 	if (P.n_work == 0) return hipSuccess;
-	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total, P.bounce_limit);
-	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, P.bounce_limit, wpw);
-	static bool attr_set = false;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
-		if (e != hipSuccess) return e;
-		attr_set = true;
-	}
-	hipLaunchKernelGGL(render_kernel<false>, dim3((P.n_work + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids,
-	                   (const void *)wave_tiles, accum, (int32_t *)nullptr, (uint32_t *)nullptr);
-	return hipGetLastError();
+	if (P.n_grids) return launch_render<false, true>(stream, P, objs, grids, wave_tiles, P.n_work, accum, nullptr, nullptr);
+	return launch_render<false, false>(stream, P, objs, grids, wave_tiles, P.n_work, accum, nullptr, nullptr);
 }
 
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub) {
 	if (P.n_work == 0) return hipSuccess;
-	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total, P.bounce_limit);
-	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, P.bounce_limit, wpw);
-	static bool attr_set = false;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
-		if (e != hipSuccess) return e;
-		attr_set = true;
-	}
 	const uint32_t n_waves = (P.n_work + 63u) / 64u;
-	hipLaunchKernelGGL(render_kernel<true>, dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids,
-	                   (const void *)list, rgb_out, path_obj, path_sub);
-	return hipGetLastError();
+	if (P.n_grids) return launch_render<true, true>(stream, P, objs, grids, list, n_waves, rgb_out, path_obj, path_sub);
+	return launch_render<true, false>(stream, P, objs, grids, list, n_waves, rgb_out, path_obj, path_sub);
 }
 
 hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8, size_t n, double sample_count, double exposure,

@@ -34,8 +34,10 @@ enum ProbeOp {
 constexpr size_t kLdsBudgetBytes = 160u * 1024u;
 // LDS bytes reserved for the grids' occupancy masks (shared by the waves of a workgroup)
 constexpr size_t kMaskBudgetBytes = 48u * 1024u;
-size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit, uint32_t waves_per_wg);
-uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total, uint32_t bounce_limit);
+// waves per workgroup of the grid instantiation (they share the LDS occupancy masks)
+constexpr uint32_t kGridWavesPerWg = 8;
+size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg);
+uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total);
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                                const WaveTile *wave_tiles, double *accum);
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
