@@ -71,8 +71,16 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	return best;
 }
 
+// Occupancy targets (waves per SIMD), measured on MI355X: the grid walk is latency-bound and gains 1.6x from 4 waves/SIMD
+// (128 VGPRs, a few dozen spills) over 2; the grid-less kernel is VALU-bound and is fastest at 3 (168 VGPRs).
+#ifndef RMD_GRID_MINW
+#define RMD_GRID_MINW 4
+#endif
+#ifndef RMD_NOGRID_MINW
+#define RMD_NOGRID_MINW 3
+#endif
 template <bool LIST, bool GRID>
-__global__ __launch_bounds__(GRID ? 512 : 64) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
+__global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_MINW : RMD_NOGRID_MINW) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
                                                      const DevGrid *__restrict__ grids, const void *__restrict__ work,
                                                      double *__restrict__ out, int32_t *__restrict__ path_obj,
                                                      uint32_t *__restrict__ path_sub) {

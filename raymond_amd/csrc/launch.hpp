@@ -35,7 +35,11 @@ constexpr size_t kLdsBudgetBytes = 160u * 1024u;
 // LDS bytes reserved for the grids' occupancy masks (shared by the waves of a workgroup)
 constexpr size_t kMaskBudgetBytes = 48u * 1024u;
 // waves per workgroup of the grid instantiation (they share the LDS occupancy masks)
-constexpr uint32_t kGridWavesPerWg = 8;
+// 4-wave workgroups: 4 of them (16 waves) fit a CU's LDS beside their staged masks and retire at a finer grain than 8-wave ones
+#ifndef RMD_GRID_WAVES
+#define RMD_GRID_WAVES 4
+#endif
+constexpr uint32_t kGridWavesPerWg = RMD_GRID_WAVES;
 size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg);
 uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total);
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,

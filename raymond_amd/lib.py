@@ -10,7 +10,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libraymond_hip.so")
+# RAYMOND_HIP_LIB selects another build of the SAME library (tuning experiments); there is still no fallback.
+LIB_PATH = os.environ.get("RAYMOND_HIP_LIB") or os.path.join(_HERE, "csrc", "libraymond_hip.so")
 
 _lib = None
 
