@@ -1,0 +1,89 @@
+// raymond_cli — the executable caller of the host mirror; follows cli_old/src/main.rs:35-198
+// (build scene -> Settings -> render_tiled -> await -> tone-map -> image file).
+//
+//   raymond_cli render <spheres|dragon[:n]> W H SPP BOUNCES out.ppm [--raw out.f64] [--gpus N] [--spi K] [--aperture R]
+//   raymond_cli mesh N out.bin            procedural stand-in mesh as raw f64 (tri_pos then tri_nrm)
+//   raymond_cli ply in.ply out.bin        Mesh::load_ply + bake_transform(0,-0.3,2.9), raw f64 as above
+//   raymond_cli tiles W H TW TH           tile generation order of render_tiled, one "left top width height" per line
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "raymond.hpp"
+
+using namespace raymond;
+
+static void dump_mesh(const Mesh &m, const std::string &path) {
+	std::ofstream f(path, std::ios::binary);
+	f.write(reinterpret_cast<const char *>(m.tri_pos.data()), (std::streamsize)(m.tri_pos.size() * 8));
+	f.write(reinterpret_cast<const char *>(m.tri_nrm.data()), (std::streamsize)(m.tri_nrm.size() * 8));
+}
+
+int main(int argc, char **argv) {
+	try {
+		if (argc >= 4 && !std::strcmp(argv[1], "mesh")) {
+			dump_mesh(lumpy_sphere_mesh(std::atoi(argv[2])), argv[3]);
+			return 0;
+		}
+		if (argc >= 4 && !std::strcmp(argv[1], "ply")) {
+			Mesh m = Mesh::load_ply(argv[2]);
+			m.bake_transform({0.0, -0.3, 2.9});
+			dump_mesh(m, argv[3]);
+			std::printf("%zu triangles\n", m.triangle_count());
+			return 0;
+		}
+		if (argc >= 6 && !std::strcmp(argv[1], "tiles")) {
+			for (const rmd_tile_rect &t : generate_tiles(std::atoi(argv[2]), std::atoi(argv[3]), {std::atoi(argv[4]), std::atoi(argv[5])}))
+				std::printf("%u %u %u %u\n", t.left, t.top, t.width, t.height);
+			return 0;
+		}
+		if (argc >= 8 && !std::strcmp(argv[1], "render")) {
+			const auto t0 = std::chrono::steady_clock::now(); // cli_old/src/main.rs:36
+			std::string what = argv[2], raw;
+			Settings st;
+			st.camera_settings.backbuffer_width = std::atoi(argv[3]);
+			st.camera_settings.backbuffer_height = std::atoi(argv[4]);
+			st.camera_settings.fov_vert = 55.0, st.camera_settings.focal_length = 2.5; // :134-141
+			st.sample_count = std::atoi(argv[5]);
+			st.bounce_limit = std::atoi(argv[6]);
+			st.tile_size = {32, 32}; // :147
+			for (int i = 8; i + 1 < argc; i += 2) {
+				if (!std::strcmp(argv[i], "--raw")) raw = argv[i + 1];
+				else if (!std::strcmp(argv[i], "--gpus")) st.worker_count = std::atoi(argv[i + 1]);
+				else if (!std::strcmp(argv[i], "--spi")) st.samples_per_iteration = std::atoi(argv[i + 1]);
+				else if (!std::strcmp(argv[i], "--aperture")) st.camera_settings.aperture_radius = std::atof(argv[i + 1]);
+			}
+			Scene scene;
+			if (what == "spheres") scene = reflective_spheres();
+			else if (what.rfind("dragon", 0) == 0) scene = gold_dragon_standin(what.size() > 7 ? std::atoi(what.c_str() + 7) : 91);
+			else throw Error(RMD_ERR_INVALID_ARGUMENT, "unknown scene " + what);
+			TaskHandle handle = render_tiled(scene, st); // :152
+			size_t progressed = 0;
+			handle.set_callback([&](const Tile &) { progressed++; });
+			std::vector<Vector3> image;
+			if (st.samples_per_iteration) {
+				// drain progress messages as they come, then collect the finished tiles
+				image.assign(st.camera_settings.backbuffer_width * st.camera_settings.backbuffer_height, Vector3{0, 0, 0});
+			}
+			image = handle.await(); // :153
+			const size_t W = st.camera_settings.backbuffer_width, H = st.camera_settings.backbuffer_height;
+			write_ppm(argv[7], tone_map(image), W, H); // :161-197
+			if (!raw.empty()) {
+				std::ofstream f(raw, std::ios::binary);
+				f.write(reinterpret_cast<const char *>(image.data()), (std::streamsize)(image.size() * 24));
+			}
+			const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			std::printf("Finished render.\nTotal render time: %.3fs\n%zu x %zu, %zu spp, %zu bounces: %.1f Msamples/s end to end\n", secs, W, H, st.sample_count,
+			            st.bounce_limit, (double)W * H * st.sample_count / secs / 1e6);
+			return 0;
+		}
+		std::fprintf(stderr, "usage: see the header of raymond_amd/host/cli.cpp\n");
+		return 2;
+	} catch (const std::exception &e) {
+		std::fprintf(stderr, "raymond_cli: %s\n", e.what());
+		return 1;
+	}
+}

@@ -1,0 +1,423 @@
+// Implementation of raymond.hpp (host side above the C-ABI).  Host code only: every pixel is produced by
+// rmd_render_tiles; nothing here evaluates a ray.
+#include "raymond.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <tuple>
+
+namespace raymond {
+
+namespace {
+void check(rmd_status s, rmd_context *ctx, const char *what) {
+	if (s != RMD_OK) {
+		const char *text = rmd_last_error(ctx);
+		throw Error(s, std::string(what) + ": " + (text ? text : ""));
+	}
+}
+} // namespace
+
+// ---------------------------------------------------------------- Mesh (core/src/geometry/mesh.rs)
+Mesh Mesh::load_ply(const std::string &path) {
+	std::ifstream in(path);
+	if (!in) throw Error(RMD_ERR_INVALID_ARGUMENT, "load_ply: cannot open " + path); // reference: unwrap() panic
+	std::string line;
+	size_t n_vertices = 0;
+	// header (:66-77): only `element vertex N` matters
+	while (std::getline(in, line)) {
+		std::istringstream tok(line);
+		std::string a, b;
+		if (!(tok >> a)) throw Error(RMD_ERR_INVALID_ARGUMENT, "load_ply: empty header line"); // tokens.next().unwrap()
+		if (a == "element") {
+			tok >> b;
+			if (b == "vertex") tok >> n_vertices;
+		} else if (a == "end_header") {
+			break;
+		}
+	}
+	struct V {
+		double p[3], n[3];
+	};
+	std::vector<V> verts;
+	verts.reserve(n_vertices);
+	for (size_t i = 0; i < n_vertices; i++) { // :80-90
+		if (!std::getline(in, line)) throw Error(RMD_ERR_INVALID_ARGUMENT, "load_ply: vertex list truncated");
+		std::istringstream tok(line);
+		std::vector<double> v;
+		double x;
+		while (tok >> x) v.push_back(x);
+		if (v.size() < 6) throw Error(RMD_ERR_INVALID_ARGUMENT, "load_ply: vertex line with fewer than 6 values");
+		verts.push_back(V{{v[0], v[1], v[2]}, {v[3], v[4], v[5]}}); // uv (:87) and tangent (:88,:101-108) are not on the hot path
+	}
+	Mesh m;
+	while (std::getline(in, line)) { // :93-118
+		std::istringstream tok(line);
+		std::vector<unsigned long> v;
+		unsigned long x;
+		while (tok >> x) v.push_back(x);
+		if (v.empty()) throw Error(RMD_ERR_INVALID_ARGUMENT, "load_ply: empty face line"); // values[0] panics
+		if (v[0] != 3) continue;                                                            // non-triangles are dropped (:116)
+		if (v.size() < 4) throw Error(RMD_ERR_INVALID_ARGUMENT, "load_ply: triangle with fewer than 3 indices");
+		for (int k = 1; k <= 3; k++) {
+			if (v[k] >= verts.size()) throw Error(RMD_ERR_INVALID_ARGUMENT, "load_ply: vertex index out of range");
+			for (int a = 0; a < 3; a++) m.tri_pos.push_back(verts[v[k]].p[a]);
+		}
+		for (int k = 1; k <= 3; k++)
+			for (int a = 0; a < 3; a++) m.tri_nrm.push_back(verts[v[k]].n[a]);
+	}
+	return m;
+}
+
+void Mesh::bake_transform(Vector3 t) {
+	for (size_t i = 0; i < tri_pos.size(); i++) tri_pos[i] += t[i % 3];
+}
+
+// ---------------------------------------------------------------- AccGrid
+std::shared_ptr<AccGrid> AccGrid::build_from_mesh(const Mesh &mesh) {
+	std::shared_ptr<AccGrid> g(new AccGrid());
+	check(rmd_grid_build_from_mesh(mesh.tri_pos.data(), mesh.tri_nrm.data(), mesh.triangle_count(), &g->build_), nullptr, "AccGrid::build_from_mesh");
+	check(rmd_grid_build_describe(g->build_, &g->desc_), nullptr, "AccGrid::build_from_mesh");
+	return g;
+}
+AccGrid::~AccGrid() { rmd_grid_build_destroy(build_); }
+
+// ---------------------------------------------------------------- render_tiled
+std::vector<rmd_tile_rect> generate_tiles(size_t width, size_t height, std::pair<size_t, size_t> ts) {
+	std::vector<rmd_tile_rect> tiles;
+	size_t x = 0, y = 0;
+	for (;;) {
+		size_t x1 = std::min(x + ts.first, width), y1 = std::min(y + ts.second, height);
+		tiles.push_back(rmd_tile_rect{(uint32_t)x, (uint32_t)y, (uint32_t)(x1 - x), (uint32_t)(y1 - y)});
+		y += ts.second;
+		if (y >= height) {
+			y = 0;
+			x += ts.first;
+		}
+		if (x >= width) break;
+	}
+	return tiles;
+}
+
+struct TaskHandle::Shared {
+	std::mutex m;
+	std::condition_variable cv;
+	std::deque<Tile> queue;      // MsQueue<Tile> (:138)
+	std::deque<Message> channel; // mpsc::channel (:139)
+	size_t alive = 0;            // alive_thread_count (:175)
+	std::string error;
+};
+
+namespace {
+
+void flatten(const Scene &scene, std::vector<rmd_object> &objs, std::vector<rmd_grid_desc> &grids) {
+	std::vector<const AccGrid *> seen;
+	for (const Object &o : scene.objects) {
+		rmd_object r;
+		std::memset(&r, 0, sizeof(r));
+		r.geometry_kind = o.geometry.kind;
+		if (o.geometry.kind == RMD_GEOM_PLANE) {
+			for (int a = 0; a < 3; a++) r.origin[a] = o.geometry.plane.origin[a], r.normal[a] = o.geometry.plane.normal[a];
+		} else if (o.geometry.kind == RMD_GEOM_SPHERE) {
+			for (int a = 0; a < 3; a++) r.origin[a] = o.geometry.sphere.origin[a];
+			r.radius = o.geometry.sphere.radius;
+		} else {
+			const AccGrid *g = o.geometry.grid.get();
+			size_t gi = std::find(seen.begin(), seen.end(), g) - seen.begin();
+			if (gi == seen.size()) {
+				seen.push_back(g);
+				grids.push_back(g->desc());
+			}
+			r.grid_index = (uint32_t)gi;
+		}
+		r.material.kind = o.material.kind;
+		for (int a = 0; a < 3; a++) r.material.color[a] = o.material.color[a];
+		r.material.roughness = o.material.roughness;
+		for (int a = 0; a < 5; a++) r.material.emission_aux[a] = o.material.aux[a];
+		objs.push_back(r);
+	}
+}
+
+// One worker = one GPU.  Pops a batch of tiles, adds `step` samples to each with ONE rmd_render_tiles call, then
+// reports them finished or re-queues them (src/trace.rs:188-221).
+void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene, Settings st, size_t batch) {
+	rmd_context *ctx = nullptr;
+	rmd_scene *dscene = nullptr;
+	double *fb = nullptr;
+	const size_t W = st.camera_settings.backbuffer_width, H = st.camera_settings.backbuffer_height;
+	try {
+		check(rmd_context_create(device, &ctx), nullptr, "rmd_context_create");
+		std::vector<rmd_object> objs;
+		std::vector<rmd_grid_desc> grids;
+		flatten(scene, objs, grids);
+		check(rmd_scene_create(ctx, objs.data(), (uint32_t)objs.size(), grids.data(), (uint32_t)grids.size(), &dscene), ctx, "rmd_scene_create");
+		check(rmd_framebuffer_alloc(ctx, (uint32_t)W, (uint32_t)H, &fb), ctx, "rmd_framebuffer_alloc");
+		rmd_camera cam;
+		std::memset(&cam, 0, sizeof(cam));
+		cam.backbuffer_width = (uint32_t)W, cam.backbuffer_height = (uint32_t)H, cam.fov_vert = st.camera_settings.fov_vert;
+		for (int a = 0; a < 3; a++) cam.position[a] = st.camera_settings.transform.position[a];
+		cam.focal_length = st.camera_settings.focal_length, cam.aperture_radius = st.camera_settings.aperture_radius;
+		std::vector<double> host(W * H * 3);
+		const size_t step = st.samples_per_iteration ? st.samples_per_iteration : st.sample_count;
+		for (;;) {
+			std::vector<Tile> mine;
+			{
+				std::lock_guard<std::mutex> lock(sh->m);
+				while (!sh->queue.empty() && mine.size() < batch) { // try_pop (:189)
+					mine.push_back(std::move(sh->queue.front()));
+					sh->queue.pop_front();
+				}
+			}
+			if (mine.empty()) break; // None -> the worker exits (:191-194)
+			// tiles of one batch may be at different sample counts; group by sample_count
+			std::map<size_t, std::vector<size_t>> by_count;
+			for (size_t i = 0; i < mine.size(); i++) by_count[mine[i].sample_count].push_back(i);
+			for (auto &grp : by_count) {
+				const size_t begin = grp.first, n = std::min(step, st.sample_count - begin);
+				std::fill(host.begin(), host.end(), 0.0);
+				std::vector<rmd_tile_rect> rects;
+				for (size_t i : grp.second) {
+					const Tile &t = mine[i];
+					rects.push_back(rmd_tile_rect{(uint32_t)t.left, (uint32_t)t.top, (uint32_t)t.width, (uint32_t)t.height});
+					for (size_t y = 0; y < t.height; y++)
+						for (size_t x = 0; x < t.width; x++)
+							std::memcpy(&host[((t.left + x) + (t.top + y) * W) * 3], t.data[x + y * t.width].data(), 24);
+				}
+				check(rmd_framebuffer_upload(ctx, host.data(), fb, host.size()), ctx, "rmd_framebuffer_upload");
+				rmd_settings rs;
+				std::memset(&rs, 0, sizeof(rs));
+				rs.bounce_limit = (uint32_t)st.bounce_limit, rs.sample_begin = (uint32_t)begin, rs.sample_count = (uint32_t)n, rs.seed = st.seed;
+				check(rmd_render_tiles(ctx, dscene, &cam, &rs, rects.data(), (uint32_t)rects.size(), fb), ctx, "rmd_render_tiles");
+				check(rmd_framebuffer_download(ctx, fb, host.data(), host.size()), ctx, "rmd_framebuffer_download");
+				for (size_t i : grp.second) {
+					Tile &t = mine[i];
+					for (size_t y = 0; y < t.height; y++)
+						for (size_t x = 0; x < t.width; x++)
+							std::memcpy(t.data[x + y * t.width].data(), &host[((t.left + x) + (t.top + y) * W) * 3], 24);
+					t.sample_count += n; // :207
+				}
+			}
+			std::lock_guard<std::mutex> lock(sh->m);
+			for (Tile &t : mine) {
+				if (t.sample_count == st.sample_count) { // :211-212
+					sh->channel.push_back(Message{Message::TileFinished, std::move(t)});
+				} else { // :214-219
+					if (st.samples_per_iteration != 0 && t.sample_count % st.samples_per_iteration == 0)
+						sh->channel.push_back(Message{Message::TileProgressed, t});
+					sh->queue.push_back(std::move(t));
+				}
+			}
+			sh->cv.notify_all();
+		}
+	} catch (const std::exception &e) {
+		std::lock_guard<std::mutex> lock(sh->m);
+		if (sh->error.empty()) sh->error = e.what();
+	}
+	if (fb) rmd_framebuffer_free(ctx, fb);
+	rmd_scene_destroy(dscene);
+	rmd_context_destroy(ctx);
+	std::lock_guard<std::mutex> lock(sh->m);
+	sh->alive--; // :192
+	sh->cv.notify_all();
+}
+
+} // namespace
+
+TaskHandle render_tiled(const Scene &scene, const Settings &settings) {
+	TaskHandle h;
+	h.settings = settings;
+	h.shared_ = std::make_shared<TaskHandle::Shared>();
+	const CameraSettings &cam = settings.camera_settings;
+	for (const rmd_tile_rect &r : generate_tiles(cam.backbuffer_width, cam.backbuffer_height, settings.tile_size)) {
+		Tile t;
+		t.left = r.left, t.top = r.top, t.width = r.width, t.height = r.height;
+		t.data.assign((size_t)r.width * r.height, Vector3{0, 0, 0});
+		h.shared_->queue.push_back(std::move(t));
+	}
+	const size_t workers = std::max<size_t>(1, settings.worker_count);
+	const size_t batch = std::max<size_t>(1, (h.shared_->queue.size() + workers * 4 - 1) / (workers * 4));
+	h.shared_->alive = workers;
+	for (size_t w = 0; w < workers; w++) h.workers_.emplace_back(worker_main, h.shared_, (int)w, scene, settings, workers == 1 ? h.shared_->queue.size() : batch);
+	return h;
+}
+
+TaskHandle::~TaskHandle() {
+	for (std::thread &t : workers_)
+		if (t.joinable()) t.join();
+}
+
+std::vector<Vector3> TaskHandle::await() {
+	const CameraSettings &cam = settings.camera_settings;
+	std::vector<Vector3> out(cam.backbuffer_width * cam.backbuffer_height, Vector3{0, 0, 0});
+	std::unique_lock<std::mutex> lock(shared_->m);
+	shared_->cv.wait(lock, [&] { return shared_->alive == 0; }); // the reference polls every 500 ms (:88-110)
+	if (!shared_->error.empty()) throw Error(RMD_ERR_HIP, shared_->error); // the reference would hang after a worker panic
+	while (!shared_->channel.empty()) {
+		Message m = std::move(shared_->channel.front());
+		shared_->channel.pop_front();
+		if (m.kind != Message::TileFinished) break; // :101-103
+		const Tile &t = m.tile;
+		for (size_t y = 0; y < t.height; y++)
+			for (size_t x = 0; x < t.width; x++) {
+				Vector3 s = t.data[x + y * t.width];
+				for (double &c : s) c /= (double)t.sample_count; // :95
+				out[x + t.left + (y + t.top) * cam.backbuffer_width] = s;
+			}
+	}
+	return out;
+}
+
+std::optional<Message> TaskHandle::poll() {
+	std::lock_guard<std::mutex> lock(shared_->m);
+	if (shared_->channel.empty()) return std::nullopt;
+	Message m = std::move(shared_->channel.front());
+	shared_->channel.pop_front();
+	return m;
+}
+
+void TaskHandle::async_await() {
+	for (;;) {
+		std::optional<Message> m;
+		{
+			std::lock_guard<std::mutex> lock(shared_->m);
+			if (shared_->channel.empty() || shared_->channel.front().kind != Message::TileProgressed) return;
+			m = std::move(shared_->channel.front());
+			shared_->channel.pop_front();
+		}
+		if (callback_) callback_(m->tile);
+	}
+}
+
+// ---------------------------------------------------------------- output stage (cli_old/src/main.rs:155-197)
+std::vector<uint8_t> tone_map(const std::vector<Vector3> &image, double exposure, double gamma) {
+	std::vector<uint8_t> out(image.size() * 3, 0);
+	for (size_t i = 0; i < image.size(); i++) {
+		double v[3];
+		bool ok = true;
+		for (int c = 0; c < 3; c++) {
+			double tm = 1.0 - std::exp(image[i][c] * -1.0 * exposure);
+			tm = std::pow(tm, 1.0 / gamma);
+			v[c] = tm * 255.0;
+			ok = ok && v[c] > -1.0 && v[c] < 256.0;
+		}
+		if (ok)
+			for (int c = 0; c < 3; c++) out[i * 3 + c] = (uint8_t)v[c];
+	}
+	return out;
+}
+
+void write_ppm(const std::string &path, const std::vector<uint8_t> &rgb8, size_t width, size_t height) {
+	std::ofstream f(path, std::ios::binary);
+	f << "P6\n" << width << " " << height << "\n255\n";
+	f.write(reinterpret_cast<const char *>(rgb8.data()), (std::streamsize)rgb8.size());
+}
+
+// ---------------------------------------------------------------- benchmark inputs (mirror of raymond_amd/scenes.py)
+namespace {
+void room_planes(Scene &s) { // cli_old/src/main.rs:77-127
+	s.objects.push_back({Geometry::Plane_({{0, -1, 0}, {0, 1, 0}}), Material::Diffuse({0.75, 0.75, 0.75}, 0.5)});
+	s.objects.push_back({Geometry::Plane_({{0, 2, 0}, {0, -1, 0}}), Material::Emission({1.5, 1.5, 1.5}, {1, 1, 1}, 0.27, 0.0)});
+	s.objects.push_back({Geometry::Plane_({{0, 0, -2}, {0, 0, 1}}), Material::Diffuse({1, 1, 1}, 0.4)});
+	s.objects.push_back({Geometry::Plane_({{0, 0, 5}, {0, 0, -1}}), Material::Diffuse({0, 0, 0}, 0.9)});
+	s.objects.push_back({Geometry::Plane_({{-2, 0, 0}, {1, 0, 0}}), Material::Diffuse({0, 0, 0}, 0.3)});
+	s.objects.push_back({Geometry::Plane_({{2, 0, 0}, {-1, 0, 0}}), Material::Diffuse({0, 0, 0}, 0.3)});
+}
+} // namespace
+
+Scene reflective_spheres() {
+	Scene s;
+	s.objects.push_back({Geometry::Sphere_({{-1.0, -0.5, 3.5}, 0.5}), Material::Diffuse({1.0, 0.0, 0.0}, 0.02)});
+	s.objects.push_back({Geometry::Sphere_({{0.74, -0.25, 3.5}, 0.75}), Material::Metal({0.05, 0.25, 1.0}, 0.01)});
+	room_planes(s);
+	return s;
+}
+
+// Same arithmetic, in the same order, as raymond_amd.scenes.lumpy_sphere_mesh (IEEE-exact operations only),
+// so both produce bit-identical triangles.
+Mesh lumpy_sphere_mesh(int n, Vector3 extent, Vector3 centre) {
+	std::map<std::tuple<int, int, int>, int> index;
+	std::vector<std::array<int, 3>> lattice;
+	auto vid = [&](int i, int j, int k) {
+		auto key = std::make_tuple(i, j, k);
+		auto it = index.find(key);
+		if (it != index.end()) return it->second;
+		int v = (int)lattice.size();
+		index.emplace(key, v);
+		lattice.push_back({i, j, k});
+		return v;
+	};
+	std::vector<std::array<int, 3>> faces;
+	const int spec[6][4] = {{0, n, 1, 2}, {0, 0, 2, 1}, {1, n, 2, 0}, {1, 0, 0, 2}, {2, n, 0, 1}, {2, 0, 1, 0}};
+	for (const auto &f : spec)
+		for (int a = 0; a < n; a++)
+			for (int b = 0; b < n; b++) {
+				auto p = [&](int da, int db) {
+					int c[3] = {0, 0, 0};
+					c[f[0]] = f[1], c[f[2]] = a + da, c[f[3]] = b + db;
+					return vid(c[0], c[1], c[2]);
+				};
+				int v00 = p(0, 0), v10 = p(1, 0), v11 = p(1, 1), v01 = p(0, 1);
+				faces.push_back({v00, v10, v11});
+				faces.push_back({v00, v11, v01});
+			}
+	const size_t nv = lattice.size();
+	std::vector<Vector3> p(nv);
+	auto t3 = [](double t) { return (4.0 * t * t - 3.0) * t; };
+	auto t2 = [](double t) { return 2.0 * t * t - 1.0; };
+	const double step = 2.0 / n;
+	Vector3 half{0, 0, 0};
+	for (size_t i = 0; i < nv; i++) {
+		double c[3], d[3];
+		for (int a = 0; a < 3; a++) c[a] = (double)lattice[i][a] * step - 1.0;
+		double len = std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+		for (int a = 0; a < 3; a++) d[a] = c[a] / len;
+		double radius = 1.0 + 0.22 * t3(d[0]) * t3(d[1]) + 0.15 * t2(d[2]) * t3(d[1]) + 0.10 * t3(d[2]) * t2(d[0]);
+		for (int a = 0; a < 3; a++) {
+			p[i][a] = d[a] * radius;
+			half[a] = std::max(half[a], std::fabs(p[i][a]));
+		}
+	}
+	Vector3 scale;
+	for (int a = 0; a < 3; a++) scale[a] = extent[a] * 0.5 / half[a];
+	for (size_t i = 0; i < nv; i++)
+		for (int a = 0; a < 3; a++) p[i][a] = p[i][a] * scale[a] + centre[a];
+	std::vector<Vector3> fn(faces.size()), vn(nv, Vector3{0, 0, 0});
+	for (size_t f = 0; f < faces.size(); f++) {
+		const Vector3 &p0 = p[faces[f][0]], &p1 = p[faces[f][1]], &p2 = p[faces[f][2]];
+		double e1[3], e2[3];
+		for (int a = 0; a < 3; a++) e1[a] = p1[a] - p0[a], e2[a] = p2[a] - p0[a];
+		fn[f] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+	}
+	for (int k = 0; k < 3; k++) // np.add.at(vn, faces[:, k], fn): sequential, corner by corner
+		for (size_t f = 0; f < faces.size(); f++)
+			for (int a = 0; a < 3; a++) vn[faces[f][k]][a] += fn[f][a];
+	for (size_t i = 0; i < nv; i++) {
+		double len = std::sqrt((vn[i][0] * vn[i][0] + vn[i][1] * vn[i][1]) + vn[i][2] * vn[i][2]);
+		for (int a = 0; a < 3; a++) vn[i][a] = vn[i][a] / len;
+	}
+	Mesh m;
+	m.tri_pos.reserve(faces.size() * 9), m.tri_nrm.reserve(faces.size() * 9);
+	for (const auto &f : faces) {
+		for (int k = 0; k < 3; k++)
+			for (int a = 0; a < 3; a++) m.tri_pos.push_back(p[f[k]][a]);
+		for (int k = 0; k < 3; k++)
+			for (int a = 0; a < 3; a++) m.tri_nrm.push_back(vn[f[k]][a]);
+	}
+	return m;
+}
+
+Scene gold_dragon_standin(int n) {
+	Mesh mesh = lumpy_sphere_mesh(n);
+	mesh.bake_transform({0.0, -0.3, 2.9}); // cli_old/src/main.rs:61
+	Scene s;
+	s.objects.push_back({Geometry::Sphere_({{-1.0, -0.5, 3.5}, 0.5}), Material::Diffuse({1.0, 0.0, 0.0}, 0.02)});
+	s.objects.push_back({Geometry::Grid(AccGrid::build_from_mesh(mesh)), Material::Metal({1.0, 1.0, 0.1}, 0.15)}); // :63,:72-75
+	room_planes(s);
+	return s;
+}
+
+} // namespace raymond
