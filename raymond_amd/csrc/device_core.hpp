@@ -172,7 +172,8 @@ RMD_DEV double geometry_schlick_ggx(V3 n, V3 v, double r) {
 // :380-382
 RMD_DEV double geometry_smith(V3 n, V3 v, V3 l, double r) { return geometry_schlick_ggx(n, v, r) * geometry_schlick_ggx(n, l, r); }
 // :384-386
-RMD_DEV V3 fresnel_schlick(double cos_theta, V3 f0) { return f0 + (mk(1.0, 1.0, 1.0) - f0) * pow(1.0 - cos_theta, 5.0); }
+RMD_DEV double pow5(double x);
+RMD_DEV V3 fresnel_schlick(double cos_theta, V3 f0) { return f0 + (mk(1.0, 1.0, 1.0) - f0) * pow5(1.0 - cos_theta); }
 // :408-416
 RMD_DEV void onb(V3 n, V3 &t, V3 &b) {
 	double sign = n.z > 0.0 ? 1.0 : -1.0;
@@ -191,26 +192,45 @@ RMD_DEV void cosine_hemisphere(double r1, double r2, V3 &dir, double &pdf) {
 	double theta = acos(sr);
 	double phi = 2.0 * kPi * r2;
 	pdf = sr;
-	double st = sin(theta), ct = cos(theta);
-	dir = mk(st * cos(phi), ct, st * sin(phi));
+	double st, ct, sp, cp;
+	sincos(theta, &st, &ct);
+	sincos(phi, &sp, &cp);
+	dir = mk(st * cp, ct, st * sp);
 }
 // :286-296
 RMD_DEV V3 importance_sample_ggx(V3 reflect, double roughness, double r1, double r2) {
 	double a = roughness * roughness;
 	double phi = 2.0 * kPi * r1;
 	double theta = a * sqrt(r2 / (1.0 - r2));
-	double st = sin(theta), ct = cos(theta);
-	V3 h = mk(st * cos(phi), ct, st * sin(phi));
+	double st, ct, sp, cp;
+	sincos(theta, &st, &ct);
+	sincos(phi, &sp, &cp);
+	V3 h = mk(st * cp, ct, st * sp);
 	V3 tg, bt;
 	onb(reflect, tg, bt);
 	return normalize(mat3_mul(tg, reflect, bt, h));
 }
 
+// x^5 for the Schlick term (src/trace.rs:385 `(1.0 - cos_theta).powf(5.0)`, a libm pow call in the reference).
+// Three multiplications: <= 1.5 ulp from the exact power, the same accuracy class as a libm pow, at ~1/60 of its cost.
+// It only scales bounce weights — never a direction or a branch — so it cannot change a hit sequence.
+RMD_DEV double pow5(double x) {
+	const double x2 = x * x;
+	const double x4 = x2 * x2;
+	return x4 * x;
+}
+RMD_DEV V3 sel(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+
 // One evaluation of the shading half of trace() (src/trace.rs:256-319) for a non-emissive hit.
-// Everything the reference computes after its recursive call depends only on values known before
-// it, so the weights are produced here and applied when the path unwinds:
+// Everything the reference computes after its recursive call depends only on values known before it, so the
+// bounce weight is produced here:
 //   diffuse  (:281-282): out = ((A (.) radiance) * cos) / d1           A = diffuse_part (.) color, d1 = prob_d * pdf
 //   specular (:315-318): out = (((A (.) radiance) * cos) / d1) / d2    A = specular, d1 = 1 - prob_d, d2 = pdf
+// Diffuse and specular lanes of a wave share one instruction stream for everything the two branches have in common —
+// the local direction (sin/cos of two angles), the frame transform, the half vector and the Fresnel term — with
+// per-lane selects choosing the branch's inputs; every lane still performs exactly its own branch's operations in
+// the reference's order.  Only the short branch-specific pieces (acos vs the GGX angle, the reflection vector, the
+// D/G terms) remain divergent.
 struct Bounce {
 	V3 A;
 	double cosv, d1, d2;
@@ -219,47 +239,60 @@ struct Bounce {
 };
 RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double metal, V3 cam_pos, Rng &rng) {
 	Bounce out;
-	V3 view = normalize(cam_pos - frag); // :256
-	V3 f0 = mk(lerp(0.04, color.x, metal), lerp(0.04, color.y, metal), lerp(0.04, color.z, metal)); // :257-258
-	double r = rng.next(); // :260
-	double prob_d = lerp(0.5, 0.0, metal); // :263
-	if (r < prob_d) {
-		double r1 = rng.next(), r2 = rng.next();
-		V3 lt, lb;
-		onb(normal, lt, lb); // :261-262
-		V3 local;
-		double pdf;
-		cosine_hemisphere(r1, r2, local, pdf);
-		V3 sw = normalize(mat3_mul(lt, normal, lb, local)); // :266
-		out.next_origin = frag + normal * 0.00001;          // :269
-		out.next_dir = sw;
-		out.cosv = fmax(dot(normal, sw), 0.0);                       // :275
-		V3 halfway = normalize(sw + view);                           // :276
-		V3 fres = fresnel_schlick(fmax(dot(halfway, view), 0.0), f0); // :277
-		V3 diffuse_part = (mk(1.0, 1.0, 1.0) - fres) * (1.0 - metal); // :279-280
-		out.A = hadamard(diffuse_part, color);
-		out.d1 = prob_d * pdf;
-		out.d2 = 1.0;
-		out.specular = false;
+	const V3 view = normalize(cam_pos - frag); // :256
+	const V3 f0 = mk(lerp(0.04, color.x, metal), lerp(0.04, color.y, metal), lerp(0.04, color.z, metal)); // :257-258
+	const double r = rng.next(); // :260
+	const double prob_d = lerp(0.5, 0.0, metal); // :263
+	const bool diffuse = r < prob_d;             // :264
+	const double r1 = rng.next(), r2 = rng.next(); // :397-398 or :287-288
+	double theta, phi, pdf_d = 0.0;
+	V3 axis;
+	if (diffuse) {
+		// uniform_sample_hemisphere (:396-406), frame around the normal (:261-262)
+		const double sr = sqrt(r1);
+		theta = acos(sr);
+		phi = 2.0 * kPi * r2;
+		pdf_d = sr;
+		axis = normal;
 	} else {
-		V3 reflect = normalize(-view - 2.0 * (-dot(view, normal) * normal)); // :285
-		double r1 = rng.next(), r2 = rng.next();                             // :287-288
-		V3 sw = importance_sample_ggx(reflect, roughness, r1, r2);
-		out.next_origin = frag + normal * 0.0001; // :300
-		out.next_dir = sw;
-		double cos_theta = dot(normal, sw); // :306
-		V3 light_dir = normalize(sw);       // :307
-		V3 halfway = normalize(light_dir + view);
-		V3 F = fresnel_schlick(dot(halfway, view), f0);
-		double D = ggx_distribution(normal, halfway, roughness);
-		double G = geometry_smith(normal, view, sw, roughness);
-		V3 nominator = (D * G) * F;
-		double denominator = 4.0 * dot(normal, view) * cos_theta + 0.001;
+		// importance_sample_ggx (:286-296), frame around the mirror direction (:285)
+		const double a = roughness * roughness;
+		phi = 2.0 * kPi * r1;
+		theta = a * sqrt(r2 / (1.0 - r2));
+		axis = normalize(-view - 2.0 * (-dot(view, normal) * normal));
+	}
+	double st, ct, sp, cp;
+	sincos(theta, &st, &ct);
+	sincos(phi, &sp, &cp);
+	const V3 local = mk(st * cp, ct, st * sp);
+	V3 tg, bt;
+	onb(axis, tg, bt);
+	const V3 sw = normalize(mat3_mul(tg, axis, bt, local)); // :266 / :295
+	out.next_origin = frag + normal * (diffuse ? 0.00001 : 0.0001); // :269 / :300
+	out.next_dir = sw;
+	const double n_dot_sw = dot(normal, sw);
+	// :276 halfway of (sample_world, view); :307-308 halfway of (normalize(sample_world), view)
+	const V3 light = diffuse ? sw : normalize(sw);
+	const V3 halfway = normalize(light + view);
+	const double h_dot_v = dot(halfway, view);
+	const double fc = diffuse ? fmax(h_dot_v, 0.0) : h_dot_v; // :277 clamps, :309 does not
+	const V3 F = f0 + (mk(1.0, 1.0, 1.0) - f0) * pow5(1.0 - fc); // fresnel_schlick :384-386
+	out.specular = !diffuse;
+	if (diffuse) {
+		out.cosv = fmax(n_dot_sw, 0.0);                            // :275
+		const V3 diffuse_part = (mk(1.0, 1.0, 1.0) - F) * (1.0 - metal); // :279-280
+		out.A = hadamard(diffuse_part, color);
+		out.d1 = prob_d * pdf_d;
+		out.d2 = 1.0;
+	} else {
+		const double D = ggx_distribution(normal, halfway, roughness);
+		const double G = geometry_smith(normal, view, sw, roughness);
+		const V3 nominator = (D * G) * F;
+		const double denominator = 4.0 * dot(normal, view) * n_dot_sw + 0.001;
 		out.A = nominator / denominator;
-		out.cosv = cos_theta;
+		out.cosv = n_dot_sw; // :306 unclamped
 		out.d1 = 1.0 - prob_d;
-		out.d2 = (D * dot(normal, halfway)) / (4.0 * dot(halfway, view)) + 0.0001; // :317
-		out.specular = true;
+		out.d2 = (D * dot(normal, halfway)) / (4.0 * h_dot_v) + 0.0001; // :317
 	}
 	return out;
 }

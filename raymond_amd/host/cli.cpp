@@ -11,6 +11,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 
 #include "raymond.hpp"
 
@@ -65,8 +66,13 @@ int main(int argc, char **argv) {
 			handle.set_callback([&](const Tile &) { progressed++; });
 			std::vector<Vector3> image;
 			if (st.samples_per_iteration) {
-				// drain progress messages as they come, then collect the finished tiles
-				image.assign(st.camera_settings.backbuffer_width * st.camera_settings.backbuffer_height, Vector3{0, 0, 0});
+				// progressive mode: hand the TileProgressed snapshots to the callback as they arrive; await() itself
+				// stops collecting at the first message that is not TileFinished (src/trace.rs:101-103)
+				while (!handle.finished()) {
+					handle.async_await();
+					std::this_thread::sleep_for(std::chrono::milliseconds(5));
+				}
+				handle.async_await();
 			}
 			image = handle.await(); // :153
 			const size_t W = st.camera_settings.backbuffer_width, H = st.camera_settings.backbuffer_height;

@@ -271,6 +271,11 @@ std::vector<Vector3> TaskHandle::await() {
 	return out;
 }
 
+bool TaskHandle::finished() const {
+	std::lock_guard<std::mutex> lock(shared_->m);
+	return shared_->alive == 0;
+}
+
 std::optional<Message> TaskHandle::poll() {
 	std::lock_guard<std::mutex> lock(shared_->m);
 	if (shared_->channel.empty()) return std::nullopt;

@@ -139,6 +139,7 @@ class TaskHandle {
 	std::vector<Vector3> await();
 	std::optional<Message> poll();        // :115-117
 	void async_await();                   // :119-134: drains leading TileProgressed messages into the callback
+	bool finished() const;                // extension: alive_thread_count == 0 (what await() polls for, :89)
 	~TaskHandle();
 	TaskHandle(TaskHandle &&) = default;
 	struct Shared; // queue + channel shared with the workers (implementation detail)
