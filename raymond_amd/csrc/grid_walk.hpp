@@ -30,6 +30,13 @@ RMD_DEV double readlane_f64(double v, int lane) {
 	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 RMD_DEV uint32_t readlane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+// value of `v` in the lane whose byte address (lane * 4) is `addr`; must be executed by every lane that is read from
+RMD_DEV double bperm_f64(int addr, double v) {
+	unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+	unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)b);
+	unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(b >> 32));
+	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 
 // One 80-byte triangle record of a cell run: v0, edge1, edge2, original triangle index.
 struct TriRecord {
@@ -70,12 +77,23 @@ RMD_DEV bool dda_step(int32_t cx, int32_t cy, int32_t cz, uint32_t idx, double t
 	return (uint32_t)c_new < (uint32_t)r_sel; // 0 <= c_new < res
 }
 
-// Per-wave LDS scratch of the cooperative triangle tests (3.75 KiB).
+// Candidates a lane may collect per round (speculative look-ahead along its own DDA path).
+#ifndef RMD_WALK_CANDIDATES
+#define RMD_WALK_CANDIDATES 4
+#endif
+constexpr uint32_t kWalkCand = RMD_WALK_CANDIDATES;
+// first probe distance of the binary search over the (at most 64 * kWalkCand) pairs of a round: half the next power of two
+constexpr uint32_t kPairSearchStart = kWalkCand <= 1 ? 32u : (kWalkCand <= 2 ? 64u : (kWalkCand <= 4 ? 128u : 256u));
+static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
+// After its first candidate a lane keeps stepping at most this many cells looking for more (the non-empty cells of
+// one surface crossing are adjacent); further cells wait for the next round.
+constexpr uint32_t kWalkLookahead = 6;
+
+// Per-wave LDS scratch of the cooperative triangle tests: one entry per (lane, candidate) pair of the round, by rank.
 struct WalkScratch {
-	double ray[6][64];  // ro.xyz, rd.xyz of the lanes with a pending cell, indexed by lane
-	uint32_t start[64]; // exclusive prefix sum of the pending cells' triangle counts, compacted by rank
-	uint32_t first[64]; // first record of the cell's run, by rank
-	uint32_t owner[64]; // lane that owns the pair, by rank
+	uint32_t start[64 * kWalkCand]; // exclusive prefix sum of the pairs' triangle counts
+	uint32_t first[64 * kWalkCand]; // first record of the pair's cell run
+	uint32_t owner[64 * kWalkCand]; // lane | candidate slot << 8
 };
 
 // Must be called by all 64 lanes of the wave in uniform control flow; `want` selects the lanes that have a ray.
@@ -155,11 +173,17 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	if (count_events && lane == 0) atomicAdd(&dbg[0], 1ull), atomicAdd(&dbg[1], (unsigned long long)__popcll(__ballot(walking)) * 0ull);
 	if (count_events) { unsigned long long wm = __ballot(walking); if (lane == 0) { atomicAdd(&dbg[1], (unsigned long long)__popcll(wm)); if (wm) atomicAdd(&dbg[2], 1ull); } }
 	for (;;) {
-		// 1. per lane: advance to the next cell that may hold triangles (ALU + LDS only).  Every cell the lane stands on
-		//    has a valid index (< n_cells, checked for the first cell above and after every step below, :129-131).
-		//    The next step is computed while the mask word of the current cell is still in flight.
+		// 1. per lane: step along the ray (ALU + LDS only), recording up to kWalkCand candidate cells (mask bit set).
+		//    A candidate is stepped over at once — speculating that it yields no hit — so that one round can gather the
+		//    adjacent non-empty cells of a surface crossing; if an earlier candidate does hit, the later ones are simply
+		//    ignored below.  Every cell the lane stands on has a valid index (< n_cells: checked for the first cell
+		//    above and after every step, acc_grid.rs:129-131).  The step is computed while the mask word is in flight.
+		uint32_t cand_idx[kWalkCand];
+#pragma unroll
+		for (uint32_t m = 0; m < kWalkCand; m++) cand_idx[m] = 0;
+		uint32_t n_cand = 0, since_first = 0;
 		if (count_events && lane == 0) atomicAdd(&dbg[3], 1ull);
-		while (walking) {
+		while (walking && n_cand < kWalkCand && since_first < kWalkLookahead) {
 			if (count_events) { unsigned long long am = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(am)) { atomicAdd(&dbg[4], 1ull); atomicAdd(&dbg[5], (unsigned long long)__popcll(am)); } }
 			bool candidate = true;
 			uint32_t word = 0xFFFFFFFFu;
@@ -174,73 +198,92 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			bool inside = dda_step(cx, cy, cz, idx, tmx, tmy, tmz, sx, sy, sz, dix, diy, diz, tdx, tdy, tdz, rx, ry, rz, ncx, ncy, ncz, nidx, ntmx, ntmy, ntmz);
 			inside = inside && nidx < (uint32_t)n_cells; // next cell past the cell array: the walk returns None there
 			candidate = candidate && ((word >> (bit & 31u)) & 1u);
-			if (candidate) break;
+			if (candidate) {
+#pragma unroll
+				for (uint32_t m = 0; m < kWalkCand; m++)
+					if (n_cand == m) cand_idx[m] = idx;
+				n_cand++;
+			}
+			since_first += n_cand ? 1u : 0u;
 			cx = ncx, cy = ncy, cz = ncz, idx = nidx, tmx = ntmx, tmy = ntmy, tmz = ntmz;
 			walking = inside;
 		}
 		RMD_STAMP(1)
-		if (__ballot(walking) == 0ull) break;
-
-		// 2. candidate cells: {first record, count} in one 8-byte gather per lane
-		uint32_t first = 0, count = 0;
-		if (walking) {
-			CellEntry e = entries[idx];
-			first = e.first, count = e.count;
+		if (__ballot(n_cand != 0u) == 0ull) {
+			if (__ballot(walking) == 0ull) break;
+			continue; // look-ahead budget used up without a candidate: keep stepping
 		}
 
-		// 3. triangle tests, distributed over the whole wave.  The (lane, cell) pairs of this round own `count` tests each;
-		//    an exclusive prefix sum over the counts numbers all tests of the round 0..T-1 in (lane, triangle) order and
-		//    the wave takes them 64 at a time: lane l of a chunk finds its pair by binary search in the scanned counts
-		//    (LDS), fetches that pair's ray from LDS and the triangle record from the cell's contiguous run (neighbouring
-		//    lanes read neighbouring 80-byte records: coalesced).  Hits are rare; they are applied by a scalar loop over
-		//    the hit ballot in ascending lane order = ascending (pair, triangle) order with a strict '<', which is the
-		//    reference's sequential scan of the cell (acc_grid.rs:135-149: closest starts at 5712515.0, first wins ties).
-		RMD_STAMP(2)
-		const bool pending = walking && count > 0u && !(debug_flags & 1u);
-		const unsigned long long pmask = __ballot(pending);
-		if (pmask != 0ull) {
-			const uint32_t n_pairs = (uint32_t)__popcll(pmask);
-			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
-			// inclusive scan of the counts over the lanes (Hillis-Steele through the LDS crossbar)
-			uint32_t incl = pending ? count : 0u;
+		// 2. the candidates' cell entries {first record, count}: all gathers of the round in flight together
+		uint32_t c_first[kWalkCand], c_count[kWalkCand];
 #pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-				if ((int)lane >= d) incl += up;
+		for (uint32_t m = 0; m < kWalkCand; m++) {
+			c_first[m] = 0, c_count[m] = 0;
+			if (m < n_cand) {
+				CellEntry e = entries[cand_idx[m]];
+				c_first[m] = e.first, c_count[m] = (debug_flags & 1u) ? 0u : e.count;
 			}
-			const uint32_t total = readlane_u32(incl, 63);
-			if (count_events && lane == 0) atomicAdd(&dbg[6], 1ull), atomicAdd(&dbg[7], (unsigned long long)n_pairs), atomicAdd(&dbg[8], (unsigned long long)total), atomicAdd(&dbg[9], (unsigned long long)((total + 63u) / 64u));
-			if (pending) {
-				scr.start[rank] = incl - count;
-				scr.first[rank] = first;
-				scr.owner[rank] = lane;
-				scr.ray[0][lane] = ro.x, scr.ray[1][lane] = ro.y, scr.ray[2][lane] = ro.z;
-				scr.ray[3][lane] = rd.x, scr.ray[4][lane] = rd.y, scr.ray[5][lane] = rd.z;
+		}
+		RMD_STAMP(2)
+
+		// 3. triangle tests, distributed over the whole wave.  The (lane, candidate) pairs of this round own `count`
+		//    tests each; an exclusive prefix sum over the counts numbers all tests of the round 0..T-1 in
+		//    (lane, candidate, triangle) order and the wave takes them 64 at a time: lane l of a chunk finds its pair by
+		//    binary search in the scanned counts (LDS), fetches that pair's ray from its owner lane's registers
+		//    (ds_bpermute) and the triangle record from the cell's contiguous run (neighbouring lanes read neighbouring
+		//    80-byte records: coalesced).  Hits are rare; they are applied by a scalar loop over the hit ballot in ascending
+		//    lane order = ascending (lane, candidate, triangle) order with a strict '<': within a candidate cell that is
+		//    the reference's sequential scan (acc_grid.rs:135-149: closest starts at 5712515.0, first wins ties), and
+		//    across candidates the earliest cell with an accepted hit wins (:151-153).
+		uint32_t my_pairs = 0, my_tests = 0;
+#pragma unroll
+		for (uint32_t m = 0; m < kWalkCand; m++) my_pairs += c_count[m] ? 1u : 0u, my_tests += c_count[m];
+		uint32_t incl_t = my_tests, incl_p = my_pairs; // inclusive scans over the lanes (Hillis-Steele through the LDS crossbar)
+#pragma unroll
+		for (int dd = 1; dd < 64; dd <<= 1) {
+			const uint32_t up_t = (uint32_t)__shfl_up((int)incl_t, dd, 64), up_p = (uint32_t)__shfl_up((int)incl_p, dd, 64);
+			if ((int)lane >= dd) incl_t += up_t, incl_p += up_p;
+		}
+		const uint32_t total = readlane_u32(incl_t, 63), n_pairs = readlane_u32(incl_p, 63);
+		if (count_events && lane == 0) atomicAdd(&dbg[6], 1ull), atomicAdd(&dbg[7], (unsigned long long)n_pairs), atomicAdd(&dbg[8], (unsigned long long)total), atomicAdd(&dbg[9], (unsigned long long)((total + 63u) / 64u));
+		bool any = false;
+		uint32_t any_slot = 0, closest_tri = 0;
+		double closest = 5712515.0;
+		if (total != 0u) {
+			{
+				uint32_t rank = incl_p - my_pairs, run = incl_t - my_tests;
+#pragma unroll
+				for (uint32_t m = 0; m < kWalkCand; m++)
+					if (c_count[m]) {
+						scr.start[rank] = run, scr.first[rank] = c_first[m], scr.owner[rank] = lane | (m << 8);
+						rank++, run += c_count[m];
+					}
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			RMD_STAMP(3)
-			double closest = 5712515.0;
-			uint32_t closest_tri = 0;
-			bool any = false;
 			for (uint32_t base = 0; base < total; base += 64u) {
 				const uint32_t w = base + lane;
 				bool h = false;
 				double t = 0.0;
 				uint32_t tri = 0, own = 0;
+				uint32_t k = 0;
 				if (w < total) {
-					uint32_t k = 0;
 #pragma unroll
-					for (uint32_t step = 32u; step > 0u; step >>= 1) {
+					for (uint32_t step = kPairSearchStart; step > 0u; step >>= 1) { // powers of two: every rank is reachable
 						const uint32_t mid = k + step;
 						if (mid < n_pairs && scr.start[mid] <= w) k = mid;
 					}
 					own = scr.owner[k];
+				}
+				// the owner lane's ray, straight from its registers (every lane takes part in the permute)
+				const int src = (int)((own & 63u) << 2);
+				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
+				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
+				if (w < total) {
 					const unsigned char *rec = runs + (size_t)(scr.first[k] + (w - scr.start[k])) * 80u;
 					const TriRecord r = load_record(rec);
-					const V3 pro = mk(scr.ray[0][own], scr.ray[1][own], scr.ray[2][own]);
-					const V3 prd = mk(scr.ray[3][own], scr.ray[4][own], scr.ray[5][own]);
 					tri = r.tri;
 					h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t);
 				}
@@ -249,31 +292,30 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				while (hits) {
 					const int l = (int)__builtin_ctzll(hits);
 					hits &= hits - 1ull;
-					const uint32_t pl = readlane_u32(own, l);
+					const uint32_t ol = readlane_u32(own, l);
 					const double tl = readlane_f64(t, l);
 					const uint32_t tril = readlane_u32(tri, l);
-					if (lane == pl && tl < closest) {
-						closest = tl;
-						closest_tri = tril;
-						any = true;
+					const uint32_t slot = ol >> 8;
+					if (lane == (ol & 63u) && (!any || slot == any_slot)) {
+						if (tl < closest) { // `closest` is still 5712515.0 until the first accepted hit
+							closest = tl;
+							closest_tri = tril;
+							any_slot = slot;
+							any = true;
+						}
 					}
 				}
 			}
 			RMD_STAMP(6)
 			__builtin_amdgcn_wave_barrier(); // the scratch is rewritten next round
-			if (any) {                       // :151-153 first cell with any hit wins
-				found = true;
-				found_t = closest;
-				found_tri = closest_tri;
-				walking = false;
-			}
 		}
-
-		// 4. lanes whose cell yielded nothing move on
-		if (walking) {
-			const bool inside = dda_step(cx, cy, cz, idx, tmx, tmy, tmz, sx, sy, sz, dix, diy, diz, tdx, tdy, tdz, rx, ry, rz, cx, cy, cz, idx, tmx, tmy, tmz);
-			walking = inside && idx < (uint32_t)n_cells;
+		if (any) { // :151-153 first cell with any hit wins
+			found = true;
+			found_t = closest;
+			found_tri = closest_tri;
+			walking = false;
 		}
+		if (__ballot(walking) == 0ull) break;
 	}
 	RMD_STAMP(7)
 #if RMD_DIAG
