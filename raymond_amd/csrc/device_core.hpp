@@ -8,6 +8,13 @@
 #include "device_types.hpp"
 
 #define RMD_DEV __device__ __forceinline__
+// Pointers read out of structs in memory are generic-address-space to the compiler, which then emits flat_load +
+// full waits; these casts state that they point to global memory (HBM), giving global_load and counted waits.
+#define RMD_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const RMD_GLOBAL T *as_global(const T *p) {
+	return (const RMD_GLOBAL T *)p;
+}
 
 namespace rmd {
 
@@ -17,6 +24,7 @@ struct V3 {
 };
 RMD_DEV V3 mk(double x, double y, double z) { return V3{x, y, z}; }
 RMD_DEV V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
+RMD_DEV V3 ld3(const RMD_GLOBAL double *p) { return V3{p[0], p[1], p[2]}; }
 RMD_DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 RMD_DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 RMD_DEV V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
@@ -135,7 +143,8 @@ RMD_DEV double heron_area(V3 a, V3 b, V3 c) {
 	double s = (ab + ac + bc) / 2.0;
 	return sqrt(s * (s - ab) * (s - ac) * (s - bc));
 }
-RMD_DEV V3 triangle_normal(const double *__restrict__ pos9, const double *__restrict__ nrm9, V3 position) {
+template <class P>
+RMD_DEV V3 triangle_normal(P pos9, P nrm9, V3 position) {
 	V3 p0 = ld3(pos9), p1 = ld3(pos9 + 3), p2 = ld3(pos9 + 6);
 	double abc = heron_area(p0, p1, p2);
 	double abp = heron_area(p0, p1, position);

@@ -43,11 +43,11 @@ struct TriRecord {
 	V3 v0, e1, e2;
 	uint32_t tri;
 };
-RMD_DEV TriRecord load_record(const unsigned char *p) {
-	const double *d = reinterpret_cast<const double *>(p);
+RMD_DEV TriRecord load_record(const RMD_GLOBAL unsigned char *p) {
+	const RMD_GLOBAL double *d = reinterpret_cast<const RMD_GLOBAL double *>(p);
 	TriRecord r;
 	r.v0 = ld3(d), r.e1 = ld3(d + 3), r.e2 = ld3(d + 6);
-	r.tri = reinterpret_cast<const uint32_t *>(p)[18];
+	r.tri = reinterpret_cast<const RMD_GLOBAL uint32_t *>(p)[18];
 	return r;
 }
 
@@ -105,8 +105,8 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
 	const uint64_t resx = g.res[0], resz = g.res[2], n_cells = g.n_cells;
 	const uint32_t mask_bits = g.mask_bits, mask_shift = g.mask_shift;
-	const CellEntry *__restrict__ entries = g.cell_entries;
-	const unsigned char *__restrict__ runs = reinterpret_cast<const unsigned char *>(g.tri_runs);
+	const RMD_GLOBAL CellEntry *entries = as_global(g.cell_entries);
+	const RMD_GLOBAL unsigned char *runs = as_global(reinterpret_cast<const unsigned char *>(g.tri_runs));
 #if RMD_DIAG
 	const bool stamp = (debug_flags & 16u) && dbg;
 	unsigned long long t_prev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -218,11 +218,11 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		uint32_t c_first[kWalkCand], c_count[kWalkCand];
 #pragma unroll
 		for (uint32_t m = 0; m < kWalkCand; m++) {
-			c_first[m] = 0, c_count[m] = 0;
-			if (m < n_cand) {
-				CellEntry e = entries[cand_idx[m]];
-				c_first[m] = e.first, c_count[m] = (debug_flags & 1u) ? 0u : e.count;
-			}
+			// unconditional gather (an unused slot reads cell 0) so that the kWalkCand loads overlap; masked afterwards
+			const uint32_t ci = m < n_cand ? cand_idx[m] : 0u;
+			const uint32_t e_first = entries[ci].first, e_count = entries[ci].count;
+			c_first[m] = e_first;
+			c_count[m] = (m < n_cand && !(debug_flags & 1u)) ? e_count : 0u;
 		}
 		RMD_STAMP(2)
 
@@ -282,7 +282,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				if (w < total) {
-					const unsigned char *rec = runs + (size_t)(scr.first[k] + (w - scr.start[k])) * 80u;
+					const RMD_GLOBAL unsigned char *rec = runs + (size_t)(scr.first[k] + (w - scr.start[k])) * 80u;
 					const TriRecord r = load_record(rec);
 					tri = r.tri;
 					h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		for (uint32_t gi = 0; gi < P.n_grids; gi++) {
 			const DevGrid &g = grids[gi];
 			if (g.mask_lds_word == 0xFFFFFFFFu) continue;
-			for (uint32_t i = tid; i < g.mask_n_words; i += blockDim.x) lmasks[g.mask_lds_word + i] = g.mask_words[i];
+			for (uint32_t i = tid; i < g.mask_n_words; i += blockDim.x) lmasks[g.mask_lds_word + i] = as_global(g.mask_words)[i];
 		}
 	}
 	__syncthreads(); // the only workgroup barrier: from here on every wave runs on its own
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 					else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin)); // sphere.rs:31-35
 					else if constexpr (GRID) {
 						const DevGrid &g = grids[o.grid_index];
-						normal = triangle_normal(g.tri_pos + (size_t)sub * 9, g.tri_nrm + (size_t)sub * 9, frag); // acc_grid.rs:85-87
+						normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, frag); // acc_grid.rs:85-87
 					} else {
 						normal = mk(0.0, 0.0, 0.0); // unreachable: a scene with grid objects runs the GRID instantiation
 					}
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void probe_scene_kernel(int mode, uint32_t g, u
 	for (uint32_t gi = 0; gi < n_grids && mask_words_total; gi++) {
 		const DevGrid &gg = grids[gi];
 		if (gg.mask_lds_word == 0xFFFFFFFFu) continue;
-		for (uint32_t i = threadIdx.x; i < gg.mask_n_words; i += 64u) lmasks[gg.mask_lds_word + i] = gg.mask_words[i];
+		for (uint32_t i = threadIdx.x; i < gg.mask_n_words; i += 64u) lmasks[gg.mask_lds_word + i] = as_global(gg.mask_words)[i];
 	}
 	__syncthreads();
 	const uint32_t *lds_masks = mask_words_total ? lmasks : nullptr;
