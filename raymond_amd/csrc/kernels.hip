@@ -1,16 +1,16 @@
 // HIP kernels of the radiance integrator for gfx950 (CDNA4).
 //
-// render_kernel<false> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel.
-//   Each lane runs the reference's per-pixel loop (src/trace.rs:197-205) for `sample_count`
-//   consecutive samples as an iterative state machine: a lane whose path ends regenerates the next
-//   sample's primary ray in place (in-lane path regeneration), so the wave stays full until the
-//   last samples.  trace()'s recursion (src/trace.rs:232-320) becomes a per-lane LDS stack of
-//   bounce weights that is unwound in the reference's evaluation order when the path terminates.
-//   The object table is staged into LDS once per wave (coalesced); the uniform closest-hit loop
-//   reads it through scalar loads, the divergent post-hit lookup reads the LDS copy.
+// render_kernel<LIST=false, GRID> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel.
+//   Each lane runs the reference's per-pixel loop (src/trace.rs:197-205) for `sample_count` consecutive samples as an
+//   iterative state machine: a lane whose path ends regenerates the next sample's primary ray in place (in-lane path
+//   regeneration), so the wave stays full until the last samples.  trace()'s recursion (src/trace.rs:232-320) becomes a
+//   running throughput: each bounce's weight is multiplied in when it is produced and the terminal radiance is scaled by
+//   the product.  The object table is staged into LDS once per workgroup (coalesced); the uniform
+//   closest-hit loop reads it through scalar loads, the divergent post-hit lookup reads the LDS copy.  GRID = true adds
+//   the wave-cooperative grid walk (grid_walk.hpp) and shares the grids' occupancy masks through LDS.
 //   MFMA is not used: there is no dense contraction anywhere on this path.
-// render_kernel<true>  — the same code driven by an explicit (x, y, sample) list, one sample per
-//   lane, radiance written out per entry (per-sample parity probe).
+// render_kernel<LIST=true, GRID>  — the same code driven by an explicit (x, y, sample) list, one sample per lane,
+//   radiance written out per entry (per-sample parity probe).
 // probe_* — device-function known-answer probes for the parity tests.
 #include <hip/hip_runtime.h>
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
                                                      double *__restrict__ out, int32_t *__restrict__ path_obj,
                                                      uint32_t *__restrict__ path_sub) {
 	extern __shared__ __align__(16) unsigned char smem[];
-	// LDS: [object table][grid occupancy masks][one bounce stack per wave]
+	// LDS: [object table][grid occupancy masks][one walk scratch per wave]
 	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
 	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
