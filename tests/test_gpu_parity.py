@@ -4,8 +4,10 @@ Levels (SURVEY.md §4 pyramid): device-function known answers -> Scene/grid inte
 per-sample radiance + hit sequence -> config-1 image -> size-independent properties
 (pass splitting, tile sharding, accumulate semantics).
 
-Tolerances (binary64 everywhere; the two sides differ only in libm: glibc vs ROCm ocml for
-sin/cos/acos/pow — +,-,*,/,sqrt are correctly rounded on both and no FMA contraction is allowed):
+Tolerances (binary64 everywhere; +,-,*,/,sqrt are correctly rounded on both sides and no FMA contraction is
+allowed.  The sides differ in libm — glibc vs ROCm ocml for sin/cos/acos — in x^5 of the Schlick term (libm pow vs
+three multiplications) and in the association of the bounce weights, which the kernel multiplies forward into a
+throughput instead of applying them on the way back up the recursion):
   * RNG, integer outputs, hit/miss flags, object/triangle ids: bit-exact;
   * arithmetic-only device functions (intersections, ONB, normals): <= 4 ulp, in practice 0;
   * libm-bound device functions: relative 1e-13;
