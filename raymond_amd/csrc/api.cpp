@@ -42,6 +42,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 	rmd_context *ctx = new (std::nothrow) rmd_context();
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_OUT_OF_MEMORY, "rmd_context_create: allocation failed");
 	ctx->device = device;
+	ctx->wave_slots = (uint32_t)prop.multiProcessorCount * 12u; // 3 waves/SIMD (grid-less kernel); the grid kernel holds 16 per CU
 	if (own_stream) {
 		hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 		if (se != hipSuccess) {
@@ -162,6 +163,7 @@ void rmd_context_destroy(rmd_context *ctx) {
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream || !ctx->owns_stream) (void)hipStreamSynchronize(ctx->stream);
 	if (ctx->d_wave_tiles) (void)hipFree(ctx->d_wave_tiles);
+	if (ctx->d_sample_buf) (void)hipFree(ctx->d_sample_buf);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -352,6 +354,32 @@ rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *
 	return RMD_OK;
 }
 
+// A wave owns 64 pixels x its sample range, so a launch with few wave tiles (an N-way tile shard, a small frame) has
+// too few, too long waves to fill 256 CUs evenly.  Such launches split every tile's samples over K waves that store
+// per-sample radiance to an HBM scratch buffer; sum_kernel then adds them in sample order — bit-identical to the
+// unsplit launch (tests/test_gpu_parity.py::test_sample_split_is_bit_exact).  RMD_SAMPLE_SPLIT=K forces K.
+static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_wave_tiles, uint32_t sample_count) {
+	uint32_t k = 1;
+	if (const char *env = std::getenv("RMD_SAMPLE_SPLIT")) {
+		k = (uint32_t)std::atoi(env);
+	} else if (n_wave_tiles != 0) {
+		if (has_grid) {
+			// mesh tiles cost ~10x wall tiles, so their waves form a long tail even on a full 1080p frame (measured: 2-way
+			// split 115.7 -> 105.2 ms; the scratch traffic, 48 B/sample, is noise next to ~2.3 us of walk per sample)
+			const uint32_t slots = ctx->wave_slots / 12u * 16u; // the grid kernel holds 16 waves per CU
+			k = (8u * slots + n_wave_tiles - 1u) / n_wave_tiles;
+			if (k < 2u) k = 2u;
+		} else if (n_wave_tiles < 4u * ctx->wave_slots) {
+			// uniform tiles: split only when wave tiles are scarce (an N-way shard); on a full frame the 48 B/sample of
+			// scratch traffic costs 3 % and buys nothing
+			k = (8u * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
+		}
+	}
+	if (k > sample_count / 8u) k = sample_count / 8u; // keep >= 8 samples per wave: path regeneration needs a run of samples
+	if (k > 64u) k = 64u;
+	return k < 2u ? 1u : k;
+}
+
 rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
                                   const rmd_tile_rect *tiles, uint32_t n_tiles, double *accum_dev) {
 	if (rmd_status s = bind(ctx)) return s;
@@ -366,8 +394,32 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		RMD_HIP(ctx, hipMemsetAsync(dbg_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
 		P.debug_counters = dbg_counters;
 	}
+	const uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
+	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes; cap it at 8 GiB
+	uint32_t per_pass = P.sample_count;
+	if (split > 1u) {
+		const size_t bytes_per_sample = (size_t)P.n_work * 64u * 3u * sizeof(double);
+		const size_t cap = (size_t)8 << 30;
+		if (bytes_per_sample * per_pass > cap) per_pass = (uint32_t)(cap / bytes_per_sample);
+		if (per_pass < 8u) per_pass = 8u;
+		const size_t need = bytes_per_sample * per_pass;
+		if (need > ctx->sample_buf_bytes) {
+			if (ctx->d_sample_buf) RMD_HIP(ctx, hipFree(ctx->d_sample_buf));
+			ctx->d_sample_buf = nullptr, ctx->sample_buf_bytes = 0;
+			RMD_HIP(ctx, hipMalloc((void **)&ctx->d_sample_buf, need));
+			ctx->sample_buf_bytes = need;
+		}
+	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-	RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, P, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev));
+	for (uint32_t done = 0; done < settings->sample_count || done == 0; done += per_pass) {
+		rmd::RenderParams Q = P;
+		Q.sample_begin = settings->sample_begin + done;
+		Q.sample_count = settings->sample_count - done < per_pass ? settings->sample_count - done : per_pass;
+		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
+		Q.sample_buf = ctx->d_sample_buf;
+		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev));
+		if (settings->sample_count == 0) break;
+	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
 	ctx->timed = true;
 	if (P.debug_flags & 24u) {
@@ -378,8 +430,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			std::fprintf(stderr, "[rmd stamps, cycles] init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
 			             h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
 		else
-		std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu pairs=%llu tests=%llu chunks=%llu\n",
-		             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+			std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu pairs=%llu tests=%llu chunks=%llu\n",
+			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
 	}
 	return RMD_OK;
 }

@@ -78,6 +78,8 @@ struct RenderParams {
 	uint32_t use_dof;
 	uint32_t n_grids;
 	uint32_t mask_words_total; // LDS words reserved for the grids' occupancy masks
+	uint32_t split_k;          // >1: each wave tile's sample range is split over split_k waves writing to sample_buf
+	double *sample_buf;        // [wave tile][sample - sample_begin][lane][3] f64, only when split_k > 1
 	uint32_t debug_flags;      // diagnostics (RMD_DEBUG env): 1 = skip triangle tests, 2 = skip grid walks (timing only, wrong results), 8 = count walk events
 	unsigned long long *debug_counters; // 16 counters, only touched when debug_flags & 8
 };

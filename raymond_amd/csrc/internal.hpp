@@ -25,6 +25,10 @@ struct rmd_context {
 	rmd::WaveTile *d_wave_tiles = nullptr;
 	uint32_t n_wave_tiles = 0;
 	size_t wave_tiles_capacity = 0;
+	// per-sample radiance scratch of split launches (api.cpp: choose_split)
+	double *d_sample_buf = nullptr;
+	size_t sample_buf_bytes = 0;
+	uint32_t wave_slots = 0; // CUs x waves per CU the render kernels can keep resident
 };
 
 struct rmd_scene {

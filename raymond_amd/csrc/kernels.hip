@@ -118,20 +118,29 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		x = w.x, y = w.y, s = w.sample, s_end = w.sample + 1u;
 		out_index = (size_t)list_idx * 3;
 	} else {
-		uint32_t wt = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
+		// work item = (wave tile, sample sub-range): with split_k > 1 the samples of a tile are spread over split_k
+		// waves (neighbouring waves, same tile) that store every sample's radiance to the sample buffer; sum_kernel then
+		// adds them to the pixel in sample order, so the result is the same sequential sum as with one wave per tile
+		const uint32_t item = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
+		const uint32_t split = P.split_k > 1u ? P.split_k : 1u;
+		const uint32_t wt = item / split, part = item % split;
 		bool have = wt < P.n_work;
 		WaveTile t = reinterpret_cast<const WaveTile *>(work)[have ? wt : 0];
 		uint32_t lx = lane & 7u, ly = lane >> 3;
-		alive = have && lx < t.w && ly < t.h && P.sample_count > 0u;
+		const uint32_t per_part = (P.sample_count + split - 1u) / split;
+		const uint32_t s_lo = part * per_part < P.sample_count ? part * per_part : P.sample_count;
+		const uint32_t s_hi = s_lo + per_part < P.sample_count ? s_lo + per_part : P.sample_count;
+		alive = have && lx < t.w && ly < t.h && s_hi > s_lo;
 		x = t.x0 + lx, y = t.y0 + ly;
-		s = P.sample_begin, s_end = P.sample_begin + P.sample_count;
-		out_index = ((size_t)x + (size_t)y * P.W) * 3;
+		s = P.sample_begin + s_lo, s_end = P.sample_begin + s_hi;
+		out_index = P.split_k > 1u ? ((size_t)wt * P.sample_count * 64u + lane) * 3 : ((size_t)x + (size_t)y * P.W) * 3;
 	}
 	const uint32_t pixel = y * P.W + x;
 	const bool writes = alive;
 
 	V3 acc = mk(0.0, 0.0, 0.0);
-	if (!LIST && alive) acc = ld3(out + out_index);
+	const bool to_buffer = !LIST && P.split_k > 1u;
+	if (!LIST && alive && !to_buffer) acc = ld3(out + out_index);
 
 	const V3 cam_pos = ld3(P.cam_pos);
 	Rng rng;
@@ -210,18 +219,42 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		}
 		if (alive && terminal) {
 			L = hadamard(T, L);
-			acc = acc + L; // src/trace.rs:203
+			if (to_buffer) {
+				double *dst = P.sample_buf + out_index + (size_t)(s - P.sample_begin) * (64u * 3u);
+				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+			} else {
+				acc = acc + L; // src/trace.rs:203
+			}
 			s++;
 			fresh = true;
 			if (s == s_end) alive = false;
 		}
 	}
 
-	if (writes) {
+	if (writes && !to_buffer) {
 		out[out_index + 0] = acc.x;
 		out[out_index + 1] = acc.y;
 		out[out_index + 2] = acc.z;
 	}
+}
+
+// Second half of a split launch: pixel += sample(s) for s = sample_begin .. +sample_count-1, strictly in that order
+// (src/trace.rs:203), reading the per-sample radiance the render kernel stored.  One wavefront per wave tile, lane = pixel;
+// every load is 24 contiguous bytes per lane, 1.5 KiB contiguous per wave.
+__global__ __launch_bounds__(64) void sum_kernel(RenderParams P, const WaveTile *__restrict__ tiles, const double *__restrict__ buf,
+                                                 double *__restrict__ out) {
+	const uint32_t wt = blockIdx.x, lane = threadIdx.x;
+	const WaveTile t = tiles[wt];
+	const uint32_t lx = lane & 7u, ly = lane >> 3;
+	if (lx >= t.w || ly >= t.h) return;
+	const size_t pix = ((size_t)(t.x0 + lx) + (size_t)(t.y0 + ly) * P.W) * 3;
+	V3 acc = ld3(out + pix);
+	const double *src = buf + ((size_t)wt * P.sample_count * 64u + lane) * 3;
+	for (uint32_t s = 0; s < P.sample_count; s++) {
+		acc = acc + ld3(src);
+		src += 64u * 3u;
+	}
+	out[pix + 0] = acc.x, out[pix + 1] = acc.y, out[pix + 2] = acc.z;
 }
 
 // ---------------------------------------------------------------- resolve + tone-map (cli_old/src/main.rs:161-181, src/trace.rs:95)
@@ -401,8 +434,12 @@ static hipError_t launch_render(hipStream_t stream, const RenderParams &P, const
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                                const WaveTile *wave_tiles, double *accum) {
 	if (P.n_work == 0) return hipSuccess;
-	if (P.n_grids) return launch_render<false, true>(stream, P, objs, grids, wave_tiles, P.n_work, accum, nullptr, nullptr);
-	return launch_render<false, false>(stream, P, objs, grids, wave_tiles, P.n_work, accum, nullptr, nullptr);
+	const uint32_t n_waves = P.n_work * (P.split_k > 1u ? P.split_k : 1u);
+	hipError_t e = P.n_grids ? launch_render<false, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
+	                         : launch_render<false, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
+	if (e != hipSuccess || P.split_k <= 1u) return e;
+	hipLaunchKernelGGL(sum_kernel, dim3(P.n_work), dim3(64), 0, stream, P, wave_tiles, (const double *)P.sample_buf, accum);
+	return hipGetLastError();
 }
 
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,

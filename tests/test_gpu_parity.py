@@ -438,3 +438,35 @@ def test_error_paths(gpu_ctx):
     assert e.value.status == abi.RMD_ERR_INVALID_ARGUMENT
     assert b"outside" in gpu_ctx.L.rmd_last_error(gpu_ctx.handle)
     fb.close(), ds.close()
+
+
+def test_sample_split_is_bit_exact(gpu_ctx, small_mesh_scene):
+    """Launches with few wave tiles split each tile's sample range over K waves + an ordered summation kernel
+    (api.cpp: choose_split).  Whatever K — forced, automatic, dividing the sample count or not — the frame must be
+    bit-identical to the one-wave-per-tile launch, including += on a pre-filled buffer and ragged edge tiles."""
+    import os
+
+    st = Settings(scenes.camera(200, 120), sample_count=37, bounce_limit=5, seed=123)
+    cam = st.camera_settings
+    tiles = generate_tiles(200, 120, (32, 32))
+    base = np.random.default_rng(5).uniform(0, 1, (120, 200, 3))
+    for scene in (scenes.reflective_spheres(), small_mesh_scene):
+        ds = render.DeviceScene(gpu_ctx, scene)
+        fb = render.Framebuffer(gpu_ctx, 200, 120)
+        results = {}
+        for k in ("1", "2", "4", "5", None):  # None = automatic choice (this small frame splits)
+            if k is None:
+                os.environ.pop("RMD_SAMPLE_SPLIT", None)
+            else:
+                os.environ["RMD_SAMPLE_SPLIT"] = k
+            try:
+                fb.upload(base)
+                render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+                results[k] = fb.download()
+            finally:
+                os.environ.pop("RMD_SAMPLE_SPLIT", None)
+        ref = results["1"]
+        assert (ref != base).any()
+        for k, img in results.items():
+            assert img.tobytes() == ref.tobytes(), "split %s differs" % k
+        fb.close(), ds.close()
