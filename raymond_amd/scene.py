@@ -55,6 +55,39 @@ class Mesh:
         self.tri_nrm = np.ascontiguousarray(tri_nrm, dtype=np.float64).reshape(-1, 9)
         assert self.tri_pos.shape == self.tri_nrm.shape
 
+    @staticmethod
+    def load_ply(path):
+        """Mesh::load_ply (mesh.rs:58-121): ASCII PLY; only `element vertex N` is read from the header, vertex lines are
+        `x y z nx ny nz [s t]`, face lines `3 i j k`; faces with another vertex count are dropped (:116).  A malformed file
+        raises (the reference panics on its unwrap()s)."""
+        with open(path) as f:
+            lines = f.read().splitlines()  # like Rust's str::lines(): no trailing empty element
+        it = iter(lines)
+        n_vertices = 0
+        for line in it:
+            tok = line.split()
+            if not tok:
+                raise ValueError("load_ply: empty header line")
+            if tok[0] == "element" and len(tok) > 2 and tok[1] == "vertex":
+                n_vertices = int(tok[2])
+            elif tok[0] == "end_header":
+                break
+        verts = []
+        for _ in range(n_vertices):
+            v = [float(t) for t in next(it).split()]
+            verts.append((v[0:3], v[3:6]))
+        pos, nrm = [], []
+        for line in it:
+            v = [int(t) for t in line.split()]
+            if not v:
+                raise ValueError("load_ply: empty face line")  # values[0] panics in the reference
+            if v[0] != 3:
+                continue
+            tri = [verts[i] for i in v[1:4]]
+            pos.append(sum((t[0] for t in tri), []))
+            nrm.append(sum((t[1] for t in tri), []))
+        return Mesh(np.array(pos, dtype=np.float64).reshape(-1, 9), np.array(nrm, dtype=np.float64).reshape(-1, 9))
+
     def bake_transform(self, translate):
         """mesh.rs:48-56: position += translate for every vertex (bounds are recomputed by the grid build)."""
         t = np.asarray(translate, dtype=np.float64)
