@@ -219,6 +219,10 @@ typedef struct rmd_grid_build rmd_grid_build; /* owns the arrays a rmd_grid_desc
  * `x + res.x*(y + z*res.z)` index (acc_grid.rs:61) running past the cell array. */
 rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const double *tri_nrm, uint64_t n_tris,
                                     rmd_grid_build **out);
+/* The same build on the GPU of `ctx` (bounds reduction, per-cell atomic counts, device scan, fill, per-cell sort);
+ * the resulting tables are byte-identical to rmd_grid_build_from_mesh's. */
+rmd_status rmd_grid_build_from_mesh_gpu(rmd_context *ctx, const double *tri_pos, const double *tri_nrm, uint64_t n_tris,
+                                        rmd_grid_build **out);
 /* Fills `desc` with pointers into `build` (valid until rmd_grid_build_destroy). */
 rmd_status rmd_grid_build_describe(const rmd_grid_build *build, rmd_grid_desc *desc);
 void rmd_grid_build_destroy(rmd_grid_build *build);

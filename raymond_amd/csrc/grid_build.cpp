@@ -11,12 +11,6 @@
 #include "../../include/raymond_hip.h"
 #include "internal.hpp"
 
-struct rmd_grid_build {
-	double bbox_min[3], bbox_max[3], cell_size[3];
-	uint32_t res[3];
-	std::vector<uint32_t> cells, mapping;
-	std::vector<double> pos, nrm;
-};
 
 namespace {
 

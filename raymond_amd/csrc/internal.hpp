@@ -41,6 +41,14 @@ struct rmd_scene {
 };
 #endif
 
+// Result of a grid build (host or GPU): owns the arrays a rmd_grid_desc points at.
+struct rmd_grid_build {
+	double bbox_min[3], bbox_max[3], cell_size[3];
+	uint32_t res[3];
+	std::vector<uint32_t> cells, mapping;
+	std::vector<double> pos, nrm;
+};
+
 namespace rmd {
 // Records `text` as the last error of `ctx` (or of the calling thread when ctx is null) and returns `status`.
 rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text);

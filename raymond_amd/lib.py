@@ -54,6 +54,7 @@ SIGNATURES = {
     "rmd_comm_destroy": (None, [_vp]),
     "rmd_reduce_framebuffer": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32]),
     "rmd_grid_build_from_mesh": (C.c_int32, [_vp, _vp, C.c_uint64, _P(_vp)]),
+    "rmd_grid_build_from_mesh_gpu": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _P(_vp)]),
     "rmd_grid_build_describe": (C.c_int32, [_vp, _P(abi.GridDesc)]),
     "rmd_grid_build_destroy": (None, [_vp]),
 }

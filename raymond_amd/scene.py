@@ -126,17 +126,18 @@ class AccGrid:
         )
 
     @staticmethod
-    def build_from_mesh(mesh):
-        """AccGrid::build_from_mesh through the product's host builder (rmd_grid_build_from_mesh)."""
+    def build_from_mesh(mesh, ctx=None):
+        """AccGrid::build_from_mesh through the product's host builder (rmd_grid_build_from_mesh), or on the GPU of
+        `ctx` (rmd_grid_build_from_mesh_gpu) — both give byte-identical tables."""
         from . import lib as _lib
 
         L = _lib.load()
         handle = C.c_void_p()
-        _lib.check(
-            L.rmd_grid_build_from_mesh(
-                mesh.tri_pos.ctypes.data_as(C.c_void_p), mesh.tri_nrm.ctypes.data_as(C.c_void_p), len(mesh), C.byref(handle)
-            )
-        )
+        pos, nrm = mesh.tri_pos.ctypes.data_as(C.c_void_p), mesh.tri_nrm.ctypes.data_as(C.c_void_p)
+        if ctx is None:
+            _lib.check(L.rmd_grid_build_from_mesh(pos, nrm, len(mesh), C.byref(handle)))
+        else:
+            _lib.check(L.rmd_grid_build_from_mesh_gpu(ctx.handle, pos, nrm, len(mesh), C.byref(handle)), ctx.handle)
         try:
             desc = abi.GridDesc()
             _lib.check(L.rmd_grid_build_describe(handle, C.byref(desc)))

@@ -114,3 +114,29 @@ def test_rccl_entry_points_world_of_one(gpu_ctx):
     assert L.rmd_reduce_framebuffer(comm, fb.ptr, fb.n, 3) == abi.RMD_ERR_INVALID_ARGUMENT
     L.rmd_comm_destroy(comm)
     fb.close()
+
+
+def test_gpu_grid_build_is_byte_identical_to_the_host_builder(gpu_ctx, oracle):
+    """SURVEY.md section 8f N4: AccGrid::build_from_mesh on the GPU (atomics + scan + per-cell sort) == host builder == oracle."""
+    from raymond_amd import lib
+    from raymond_amd.scene import AccGrid, Mesh
+
+    rng = np.random.default_rng(7)
+    soup = Mesh((rng.uniform(-1, 1, size=(3000, 1, 3)) * np.array([1.0, 0.8, 0.5]) + rng.normal(scale=0.08, size=(3000, 3, 3))).reshape(-1, 9),
+                rng.normal(size=(3000, 9)))
+    meshes = [scenes.lumpy_sphere_mesh(13), scenes.lumpy_sphere_mesh(40), scenes.lumpy_sphere_mesh(91), soup]
+    for m in meshes[:3]:
+        m.bake_transform((0.0, -0.3, 2.9))
+    for m in meshes:
+        host, dev = AccGrid.build_from_mesh(m), AccGrid.build_from_mesh(m, ctx=gpu_ctx)
+        assert np.array_equal(host.resolution, dev.resolution)
+        assert host.bbox_min.tobytes() == dev.bbox_min.tobytes() and host.bbox_max.tobytes() == dev.bbox_max.tobytes()
+        assert host.cell_size.tobytes() == dev.cell_size.tobytes()
+        assert host.cells.tobytes() == dev.cells.tobytes()
+        assert host.mapping_table.tobytes() == dev.mapping_table.tobytes()
+    rc, og = oracle.grid_build(meshes[1])
+    assert rc == 0 and og.mapping_table.tobytes() == AccGrid.build_from_mesh(meshes[1], ctx=gpu_ctx).mapping_table.tobytes()
+    bad = scenes.lumpy_sphere_mesh(6, extent=(2.0, 0.5, 3.0))  # res.z > res.y: the reference's index quirk panics
+    with pytest.raises(lib.RaymondError) as e:
+        AccGrid.build_from_mesh(bad, ctx=gpu_ctx)
+    assert e.value.status == abi.RMD_ERR_GRID_INDEX
