@@ -278,9 +278,9 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		const uint64_t covered = any_nonempty ? last_nonempty + 1 : 0;
 		const size_t budget_words = rmd::kMaskBudgetBytes / 4 / n_grids;
 		uint32_t shift = 0;
-		while (((covered >> shift) + 31) / 32 > budget_words) shift++;
+		while (((covered >> shift) + 31) / 32 + 1 > budget_words) shift++;
 		const uint64_t bits = covered ? ((covered - 1) >> shift) + 1 : 0;
-		std::vector<uint32_t> mask((size_t)((bits + 31) / 32) + (bits == 0 ? 1 : 0), 0u);
+		std::vector<uint32_t> mask((size_t)((bits + 31) / 32) + 1, 0u); // + one all-zero word: indices past the mask read it
 		for (uint64_t c = 0; c < covered; c++)
 			if (entries[c].count) mask[(c >> shift) >> 5] |= 1u << ((c >> shift) & 31u);
 		d.mask_bits = (uint32_t)bits, d.mask_shift = shift, d.mask_n_words = (uint32_t)mask.size();

@@ -87,7 +87,10 @@ constexpr uint32_t kPairSearchStart = kWalkCand <= 1 ? 32u : (kWalkCand <= 2 ? 6
 static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 // After its first candidate a lane keeps stepping at most this many cells looking for more (the non-empty cells of
 // one surface crossing are adjacent); further cells wait for the next round.
-constexpr uint32_t kWalkLookahead = 6;
+#ifndef RMD_WALK_LOOKAHEAD
+#define RMD_WALK_LOOKAHEAD 6
+#endif
+constexpr uint32_t kWalkLookahead = RMD_WALK_LOOKAHEAD;
 
 // Per-wave LDS scratch of the cooperative triangle tests: one entry per (lane, candidate) pair of the round, by rank.
 struct WalkScratch {
@@ -105,6 +108,9 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
 	const uint64_t resx = g.res[0], resz = g.res[2], n_cells = g.n_cells;
 	const uint32_t mask_bits = g.mask_bits, mask_shift = g.mask_shift;
+	const uint32_t mask_pad_bit = g.mask_n_words * 32u - 32u; // first bit of the all-zero word that ends every mask (api.cpp)
+	// with res.z <= res.y no in-range cell can index past the cell array (Q5), so the per-step test is dropped
+	const bool idx_can_leave_array = (resx - 1u) + resx * ((g.res[1] - 1u) + (resz - 1u) * resz) >= n_cells;
 	const RMD_GLOBAL CellEntry *entries = as_global(g.cell_entries);
 	const RMD_GLOBAL unsigned char *runs = as_global(reinterpret_cast<const unsigned char *>(g.tri_runs));
 #if RMD_DIAG
@@ -181,30 +187,33 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		uint32_t cand_idx[kWalkCand];
 #pragma unroll
 		for (uint32_t m = 0; m < kWalkCand; m++) cand_idx[m] = 0;
-		uint32_t n_cand = 0, since_first = 0;
+		// `budget` = steps this lane may still take in this round: unlimited until its first candidate, kWalkLookahead
+		// after it, 0 once kWalkCand candidates are recorded.
+		uint32_t n_cand = 0, budget = 0x7FFFFFFFu;
 		if (count_events && lane == 0) atomicAdd(&dbg[3], 1ull);
-		while (walking && n_cand < kWalkCand && since_first < kWalkLookahead) {
+		while (walking && budget != 0u) {
 			if (count_events) { unsigned long long am = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(am)) { atomicAdd(&dbg[4], 1ull); atomicAdd(&dbg[5], (unsigned long long)__popcll(am)); } }
-			bool candidate = true;
-			uint32_t word = 0xFFFFFFFFu;
-			const uint32_t bit = idx >> mask_shift;
+			// occupancy bit of the current cell: indices past the mask read the zero word that pads it
+			uint32_t word = 0xFFFFFFFFu, bit = 0;
 			if (lds_mask) {
-				candidate = bit < mask_bits;
-				word = lds_mask[candidate ? (bit >> 5) : 0u];
+				bit = idx >> mask_shift;
+				bit = bit < mask_bits ? bit : mask_pad_bit;
+				word = lds_mask[bit >> 5];
 			}
 			int32_t ncx, ncy, ncz;
 			uint32_t nidx;
 			double ntmx, ntmy, ntmz;
 			bool inside = dda_step(cx, cy, cz, idx, tmx, tmy, tmz, sx, sy, sz, dix, diy, diz, tdx, tdy, tdz, rx, ry, rz, ncx, ncy, ncz, nidx, ntmx, ntmy, ntmz);
-			inside = inside && nidx < (uint32_t)n_cells; // next cell past the cell array: the walk returns None there
-			candidate = candidate && ((word >> (bit & 31u)) & 1u);
+			if (idx_can_leave_array) inside = inside && nidx < (uint32_t)n_cells; // next cell past the cell array: the walk returns None there
+			const bool candidate = (word >> (bit & 31u)) & 1u;
+			budget--;
 			if (candidate) {
 #pragma unroll
 				for (uint32_t m = 0; m < kWalkCand; m++)
 					if (n_cand == m) cand_idx[m] = idx;
 				n_cand++;
+				budget = n_cand == kWalkCand ? 0u : (budget < kWalkLookahead ? budget : kWalkLookahead);
 			}
-			since_first += n_cand ? 1u : 0u;
 			cx = ncx, cy = ncy, cz = ncz, idx = nidx, tmx = ntmx, tmy = ntmy, tmz = ntmz;
 			walking = inside;
 		}
