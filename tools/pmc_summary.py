@@ -7,8 +7,13 @@ for d in sys.argv[1:]:
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "render_kernel" not in r["Kernel_Name"]:
+            kn = r["Kernel_Name"]
+            if "render_kernel" in kn:
+                tag = ""
+            elif "sum_kernel" in kn:
+                tag = "[sum_kernel]"
+            else:
                 continue
-            per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            per[r["Counter_Name"] + tag].append(float(r["Counter_Value"]))
         for k, v in per.items():
             print("%-28s %-24s n=%d avg/dispatch=%.6g" % (os.path.basename(d), k, len(v), sum(v) / len(v)))
