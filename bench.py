@@ -83,6 +83,11 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    # RMD_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box: the ranks share device 0 and reduce over gloo
+    # (RCCL refuses two ranks on one GPU).  The driver's runs use the default: one rank per GPU, backend nccl = RCCL.
+    backend = os.environ.get("RMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -90,14 +95,20 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from raymond_amd import render, scenes, shard
     from raymond_amd.scene import generate_tiles, tile_array
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     def setup(name, spp):
         st = scenes.config_settings(name, spp=spp)
@@ -124,7 +135,14 @@ def main():
             fb_t.zero_()
             render.render_tiles(ctx, ds, cam, st, arr, fb, 0, st.sample_count, sync=False)
             if reduce and dist is not None:
-                shard.reduce_framebuffer(dist, fb_t, root=0)
+                if backend == "nccl":
+                    shard.reduce_framebuffer(dist, fb_t, root=0)
+                else:  # rehearsal: stage through the host
+                    torch.cuda.synchronize(dev)
+                    host = fb_t.cpu()
+                    shard.reduce_framebuffer(dist, host, root=0)
+                    if rank == 0:
+                        fb_t.copy_(host)
 
         for _ in range(warmup):
             step()
@@ -140,7 +158,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         checksum = float(fb_t.sum().item()) if rank == 0 else 0.0
@@ -239,7 +257,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

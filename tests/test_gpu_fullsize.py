@@ -140,3 +140,32 @@ def test_gpu_grid_build_is_byte_identical_to_the_host_builder(gpu_ctx, oracle):
     with pytest.raises(lib.RaymondError) as e:
         AccGrid.build_from_mesh(bad, ctx=gpu_ctx)
     assert e.value.status == abi.RMD_ERR_GRID_INDEX
+
+
+def test_bench_contract_and_two_rank_rehearsal(gpu_ctx):
+    """bench.py prints ONE JSON line with the driver's keys; a 2-rank run (rehearsal mode: both ranks on this GPU, reduce
+    over gloo — RCCL refuses two ranks on one device) reduces to the same frame as the 1-rank run, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "1", "--spp", "24", "--no-cpu-baseline", "--no-roofline-leg"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=300, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    lines = [l for l in one.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1
+    a = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in a, key
+    assert a["unit"] == "Msamples/s" and a["n_gpus"] == 1 and a["dtype"] == "f64" and a["vs_baseline"] is None and "workload" in a["config"]
+    assert abs(a["value"] - 1920 * 1080 * 24 / (a["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * a["value"]
+    env = dict(os.environ, RMD_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    b = json.loads([l for l in two.stdout.split("\n") if l.startswith("{")][0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert b["kernel"]["checksum"] == a["kernel"]["checksum"]  # every pixel is non-zero on exactly one rank
