@@ -72,8 +72,35 @@ struct Rng {
 		}
 		uint32_t lo = (draw & 1u) ? w2 : w0, hi = (draw & 1u) ? w3 : w1;
 		draw++;
+		return to_unit(lo, hi);
+	}
+	static RMD_DEV double to_unit(uint32_t lo, uint32_t hi) {
 		uint64_t bits = (((uint64_t)hi << 32) | lo) >> 11;
 		return (double)bits * (1.0 / 9007199254740992.0);
+	}
+	// The three draws of one shaded depth (r, r1, r2 = draws d, d+1, d+2; src/trace.rs:260 and :397-398 / :287-288) in one
+	// go.  Block (d+2)>>1 is needed by every lane — its first half is r2 for even d, its two halves are r1 and r2 for
+	// odd d — so it is evaluated unconditionally; block d>>1 only by the even-d lanes (odd-d lanes still hold its
+	// second half from the previous depth).  Lanes of a wave sit at both parities, so three separate next() calls would
+	// each run a Philox for part of the wave; this runs two.  Same values as three next() calls.
+	RMD_DEV void next3(double &r, double &r1, double &r2) {
+		const uint32_t d = draw, b1 = (d + 2u) >> 1;
+		uint32_t v0, v1, v2, v3;
+		philox4x32_10(pixel, sample, b1, 0u, k0, k1, v0, v1, v2, v3);
+		if (d & 1u) {
+			if (blk != (d >> 1)) philox4x32_10(pixel, sample, d >> 1, 0u, k0, k1, w0, w1, w2, w3); // never after jitter/DoF/next3
+			r = to_unit(w2, w3);
+			r1 = to_unit(v0, v1);
+			r2 = to_unit(v2, v3);
+		} else {
+			uint32_t u0, u1, u2, u3;
+			philox4x32_10(pixel, sample, d >> 1, 0u, k0, k1, u0, u1, u2, u3);
+			r = to_unit(u0, u1);
+			r1 = to_unit(u2, u3);
+			r2 = to_unit(v0, v1);
+		}
+		w0 = v0, w1 = v1, w2 = v2, w3 = v3, blk = b1;
+		draw = d + 3u;
 	}
 };
 
@@ -250,10 +277,10 @@ RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double meta
 	Bounce out;
 	const V3 view = normalize(cam_pos - frag); // :256
 	const V3 f0 = mk(lerp(0.04, color.x, metal), lerp(0.04, color.y, metal), lerp(0.04, color.z, metal)); // :257-258
-	const double r = rng.next(); // :260
+	double r, r1, r2; // :260, then :397-398 or :287-288
+	rng.next3(r, r1, r2);
 	const double prob_d = lerp(0.5, 0.0, metal); // :263
 	const bool diffuse = r < prob_d;             // :264
-	const double r1 = rng.next(), r2 = rng.next(); // :397-398 or :287-288
 	double theta, phi, pdf_d = 0.0;
 	V3 axis;
 	if (diffuse) {
