@@ -164,6 +164,7 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->stream || !ctx->owns_stream) (void)hipStreamSynchronize(ctx->stream);
 	if (ctx->d_wave_tiles) (void)hipFree(ctx->d_wave_tiles);
 	if (ctx->d_sample_buf) (void)hipFree(ctx->d_sample_buf);
+	if (ctx->d_debug_counters) (void)hipFree(ctx->d_debug_counters);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -388,11 +389,10 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	if (rmd_status s = prepare_wave_tiles(ctx, camera, tiles, n_tiles)) return s;
 	rmd::RenderParams P = rmd::make_params(scene, camera, settings);
 	P.n_work = ctx->n_wave_tiles;
-	static unsigned long long *dbg_counters = nullptr;
 	if (P.debug_flags & 24u) {
-		if (!dbg_counters) RMD_HIP(ctx, hipMalloc((void **)&dbg_counters, 16 * sizeof(unsigned long long)));
-		RMD_HIP(ctx, hipMemsetAsync(dbg_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
-		P.debug_counters = dbg_counters;
+		if (!ctx->d_debug_counters) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_debug_counters, 16 * sizeof(unsigned long long)));
+		RMD_HIP(ctx, hipMemsetAsync(ctx->d_debug_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+		P.debug_counters = ctx->d_debug_counters;
 	}
 	const uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
 	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes; cap it at 8 GiB
@@ -424,7 +424,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	ctx->timed = true;
 	if (P.debug_flags & 24u) {
 		unsigned long long h[16];
-		RMD_HIP(ctx, hipMemcpyAsync(h, dbg_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+		RMD_HIP(ctx, hipMemcpyAsync(h, ctx->d_debug_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
 		RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		if (P.debug_flags & 16u)
 			std::fprintf(stderr, "[rmd stamps, cycles] init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",

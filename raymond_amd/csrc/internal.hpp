@@ -29,6 +29,7 @@ struct rmd_context {
 	double *d_sample_buf = nullptr;
 	size_t sample_buf_bytes = 0;
 	uint32_t wave_slots = 0; // CUs x waves per CU the render kernels can keep resident
+	unsigned long long *d_debug_counters = nullptr; // walk diagnostics (DIAG builds, RMD_DEBUG=8|16)
 };
 
 struct rmd_scene {

@@ -419,12 +419,10 @@ static hipError_t launch_render(hipStream_t stream, const RenderParams &P, const
                                 uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub) {
 	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total);
 	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, wpw);
-	static bool attr_set = false;
-	if (!attr_set) {
+	if (lds > 64u * 1024u) { // above the default dynamic-LDS limit: opt in on the current device (cheap, and correct per device)
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<LIST, GRID>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                   (int)kLdsBudgetBytes);
 		if (e != hipSuccess) return e;
-		attr_set = true;
 	}
 	hipLaunchKernelGGL((render_kernel<LIST, GRID>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
 	                   path_obj, path_sub);
@@ -469,13 +467,12 @@ hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in
 hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,
                               const DevGrid *grids, uint32_t n_grids, uint32_t mask_words_total, const double *rays, double *out) {
 	if (n == 0) return hipSuccess;
-	static bool attr_set = false;
-	if (!attr_set) {
+	const size_t probe_lds = (size_t)((mask_words_total + 3u) & ~3u) * 4u + sizeof(WalkScratch);
+	if (probe_lds > 64u * 1024u) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_scene_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
 		if (e != hipSuccess) return e;
-		attr_set = true;
 	}
-	hipLaunchKernelGGL(probe_scene_kernel, dim3((n + 63u) / 64u), dim3(64), (size_t)((mask_words_total + 3u) & ~3u) * 4u + sizeof(WalkScratch), stream, mode, g, n, objs,
+	hipLaunchKernelGGL(probe_scene_kernel, dim3((n + 63u) / 64u), dim3(64), probe_lds, stream, mode, g, n, objs,
 	                   n_objects, grids, n_grids, mask_words_total, rays, out);
 	return hipGetLastError();
 }
