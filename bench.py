@@ -60,6 +60,29 @@ def algorithmic_bytes_per_sample(name, spp, counters):
     return 8.0 * c["cells"] / n + 76.0 * c["tri_tests"] / n + 72.0 * c["mesh_hits"] / n + 24.0 / spp
 
 
+def usable_cpus():
+    """Threads worth starting: the affinity mask, capped by the cgroup CPU quota when there is one (a container may list
+    256 CPUs but be granted 16 cores' worth of time; more runnable threads than that only add contention)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:  # cgroup v1
+                q, period = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 def load_traffic(name):
     """Measured HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -233,7 +256,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
 
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores, quota = usable_cpus()
         # calibrate on 1 spp, then size the sample for ~15 s of CPU work (the rate is spp-independent)
         st, cam, sc, tiles, _ = setup(name, 1)
         osc = oracle_lib.OracleScene(sc)
@@ -248,10 +271,18 @@ def main():
         n = cam.backbuffer_width * cam.backbuffer_height * cpu_spp
         out["cpu_baseline"] = {
             "value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%s at %dx%d, %d spp (%.1f M samples, %.1f s): reference-equivalent C++ restatement (oracle/), worker pool of %d threads as num_cpus::get(), 32x32 tiles, g++ -O2"
-            % (name, cam.backbuffer_width, cam.backbuffer_height, cpu_spp, n / 1e6, dt, cores),
+            "sample": "%s at %dx%d, %d spp (%.1f M samples, %.1f s): reference-equivalent C++ restatement (oracle/), worker pool of %d threads (num_cpus::get() capped by the cgroup CPU quota%s), 32x32 tiles, g++ -O2"
+            % (name, cam.backbuffer_width, cam.backbuffer_height, cpu_spp, n / 1e6, dt, cores, "" if quota is None else " of %.1f CPUs" % quota),
         }
         out["speedup_vs_cpu_baseline"] = round(value / (n / dt / 1e6), 1)
+        # the reference's README quotes its ReflectiveSpheres time on a "4 core i5" (0.268 Msamples/s at 592x340): same port on 4 threads
+        spp4 = max(1, min(cpu_spp, int(8.0 / max(t1 * cores / 4.0, 1e-3))))
+        st4 = scenes.config_settings(name, spp=spp4)
+        t0 = time.perf_counter()
+        osc.render_tiles(cam, st4, tiles, threads=4)
+        dt4 = time.perf_counter() - t0
+        out["cpu_baseline_4_threads"] = {"value": round(cam.backbuffer_width * cam.backbuffer_height * spp4 / dt4 / 1e6, 4), "unit": "Msamples/s", "cores": 4,
+                                         "kind": "port", "sample": "%s at %dx%d, %d spp, %.1f s" % (name, cam.backbuffer_width, cam.backbuffer_height, spp4, dt4)}
 
     ctx.close()
     if rank == 0:
