@@ -277,7 +277,11 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		}
 		// occupancy bitmask for LDS: bit i covers cells [i << shift, (i+1) << shift); only up to the last non-empty cell
 		const uint64_t covered = any_nonempty ? last_nonempty + 1 : 0;
-		const size_t budget_words = rmd::kMaskBudgetBytes / 4 / n_grids;
+		size_t budget_bytes = rmd::kMaskBudgetBytes;
+		if (const char *env = std::getenv("RMD_MASK_BUDGET")) budget_bytes = (size_t)std::atol(env); // test hook: force coarse masks
+		if (budget_bytes < 64) budget_bytes = 64;
+		if (budget_bytes > rmd::kMaskBudgetBytes) budget_bytes = rmd::kMaskBudgetBytes;
+		const size_t budget_words = budget_bytes / 4 / n_grids;
 		uint32_t shift = 0;
 		while (((covered >> shift) + 31) / 32 + 1 > budget_words) shift++;
 		const uint64_t bits = covered ? ((covered - 1) >> shift) + 1 : 0;

@@ -470,3 +470,80 @@ def test_sample_split_is_bit_exact(gpu_ctx, small_mesh_scene):
         for k, img in results.items():
             assert img.tobytes() == ref.tobytes(), "split %s differs" % k
         fb.close(), ds.close()
+
+
+def test_degenerate_scenes_and_frames(gpu_ctx, oracle):
+    """Empty scene (every ray misses), 1x1 frame, a single 3x5 tile off the 8-pixel lattice."""
+    from raymond_amd.scene import Scene
+
+    empty = Scene()
+    st = Settings(scenes.camera(40, 24), sample_count=3, bounce_limit=5, seed=1)
+    ds = render.DeviceScene(gpu_ctx, empty)
+    fb = render.Framebuffer(gpu_ctx, 40, 24)
+    render.render_tiles(gpu_ctx, ds, st.camera_settings, st, generate_tiles(40, 24, (32, 32)), fb)
+    assert not fb.download().any()
+    fb.close(), ds.close()
+    sc = scenes.reflective_spheres()
+    osc = oracle.OracleScene(sc)
+    for (w, h, tiles) in ((1, 1, [(0, 0, 1, 1)]), (37, 29, [(5, 3, 3, 5), (20, 11, 17, 18)])):
+        st = Settings(scenes.camera(w, h), sample_count=6, bounce_limit=4, seed=17)
+        ds = render.DeviceScene(gpu_ctx, sc)
+        fb = render.Framebuffer(gpu_ctx, w, h)
+        render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
+        dev = fb.download()
+        ref = osc.render_tiles(st.camera_settings, st, tiles)
+        assert rel_close(dev, ref, 1e-9).all(axis=2).mean() >= 0.98
+        covered = np.zeros((h, w), dtype=bool)
+        for (l, t, tw, th) in tiles:
+            covered[t : t + th, l : l + tw] = True
+        assert not dev[~covered].any()
+        fb.close(), ds.close()
+
+
+def test_two_grids_and_coarse_masks(gpu_ctx, oracle):
+    """A scene with two AccGrids (two occupancy masks in LDS, objects interleaved with planes), rendered with the
+    exact masks and with a mask budget so small that one bit covers many cells (false-positive candidates)."""
+    import os
+
+    from raymond_amd.scene import AccGrid, Grid, Material, Object, Plane, Scene, Sphere
+
+    def mesh(n, centre, extent):
+        m = scenes.lumpy_sphere_mesh(n, extent=extent, centre=centre)
+        m.bake_transform((0.0, -0.3, 2.9))
+        return m
+
+    sc = Scene()
+    sc.objects.append(Object(Grid(AccGrid.build_from_mesh(mesh(14, (-0.9, 0.0, 0.0), (1.2, 1.0, 0.8)))), Material.Metal((1.0, 1.0, 0.1), 0.15)))
+    sc.objects.append(Object(Plane((0.0, -1.0, 0.0), (0.0, 1.0, 0.0)), Material.Diffuse((0.75, 0.75, 0.75), 0.5)))
+    sc.objects.append(Object(Grid(AccGrid.build_from_mesh(mesh(10, (0.9, 0.1, 0.3), (1.0, 1.1, 0.7)))), Material.Diffuse((0.2, 0.8, 0.3), 0.4)))
+    sc.objects.append(Object(Plane((0.0, 2.0, 0.0), (0.0, -1.0, 0.0)), Material.Emission((1.5, 1.5, 1.5))))
+    sc.objects.append(Object(Sphere((0.0, -0.6, 2.2), 0.3), Material.Diffuse((1.0, 0.0, 0.0), 0.02)))
+    st = Settings(scenes.camera(320, 180), sample_count=1, bounce_limit=5, seed=77)
+    cam = st.camera_settings
+    rng = np.random.default_rng(3)
+    n = 12000
+    xy = np.stack([rng.integers(0, 320, n), rng.integers(0, 180, n)], axis=1).astype(np.uint32)
+    smp = rng.integers(0, 1000, n).astype(np.uint32)
+    osc = oracle.OracleScene(sc)
+    orgb = osc.trace_samples(cam, st, xy, smp)
+    for budget in (None, "256"):
+        if budget:
+            os.environ["RMD_MASK_BUDGET"] = budget
+        try:
+            ds = render.DeviceScene(gpu_ctx, sc)
+        finally:
+            os.environ.pop("RMD_MASK_BUDGET", None)
+        drgb, dpo, dps = probe.trace_samples(gpu_ctx, ds, cam, st, xy, smp, paths=True)
+        close = rel_close(drgb, orgb, 1e-9).all(axis=1)
+        assert close.mean() >= 0.999, (budget, close.mean())
+        assert (dpo == 0).any(axis=1).mean() > 0.02 and (dpo == 2).any(axis=1).mean() > 0.02  # both meshes are hit
+        # a full-frame launch takes the same path (tile mode, sample splitting on)
+        fb = render.Framebuffer(gpu_ctx, 320, 180)
+        render.render_tiles(gpu_ctx, ds, cam, st, generate_tiles(320, 180, (32, 32)), fb)
+        img = fb.download()
+        assert np.isfinite(img).all()
+        if budget is None:
+            exact = img
+        else:
+            assert img.tobytes() == exact.tobytes()  # the mask only filters: coarse or exact, same image
+        fb.close(), ds.close()
