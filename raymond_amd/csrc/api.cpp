@@ -42,6 +42,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 	rmd_context *ctx = new (std::nothrow) rmd_context();
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_OUT_OF_MEMORY, "rmd_context_create: allocation failed");
 	ctx->device = device;
+	ctx->n_cus = (uint32_t)prop.multiProcessorCount;
 	ctx->wave_slots = (uint32_t)prop.multiProcessorCount * 12u; // 3 waves/SIMD (grid-less kernel); the grid kernel holds 16 per CU
 	if (own_stream) {
 		hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -165,6 +166,7 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->d_wave_tiles) (void)hipFree(ctx->d_wave_tiles);
 	if (ctx->d_sample_buf) (void)hipFree(ctx->d_sample_buf);
 	if (ctx->d_debug_counters) (void)hipFree(ctx->d_debug_counters);
+	if (ctx->d_wavefront_ws) (void)hipFree(ctx->d_wavefront_ws);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -397,6 +399,23 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		if (!ctx->d_debug_counters) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_debug_counters, 16 * sizeof(unsigned long long)));
 		RMD_HIP(ctx, hipMemsetAsync(ctx->d_debug_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
 		P.debug_counters = ctx->d_debug_counters;
+	}
+	// Scenes with grids can also be evaluated by the streaming pipeline of wavefront.hip (RMD_GRID_MODE=wavefront):
+	// same result bit for bit, different schedule.
+	const char *mode = std::getenv("RMD_GRID_MODE");
+	if (scene->n_grids != 0 && mode && std::strcmp(mode, "wavefront") == 0 && !(P.debug_flags & 24u)) {
+		const size_t need = rmd::wavefront_workspace_bytes(P.n_work);
+		if (need > ctx->wavefront_ws_bytes) {
+			if (ctx->d_wavefront_ws) RMD_HIP(ctx, hipFree(ctx->d_wavefront_ws));
+			ctx->d_wavefront_ws = nullptr, ctx->wavefront_ws_bytes = 0;
+			RMD_HIP(ctx, hipMalloc(&ctx->d_wavefront_ws, need));
+			ctx->wavefront_ws_bytes = need;
+		}
+		RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+		RMD_HIP(ctx, rmd::launch_wavefront(ctx->stream, P, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, ctx->d_wavefront_ws, ctx->n_cus));
+		RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+		ctx->timed = true;
+		return RMD_OK;
 	}
 	const uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
 	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes; cap it at 8 GiB

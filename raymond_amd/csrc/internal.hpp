@@ -29,6 +29,9 @@ struct rmd_context {
 	double *d_sample_buf = nullptr;
 	size_t sample_buf_bytes = 0;
 	uint32_t wave_slots = 0; // CUs x waves per CU the render kernels can keep resident
+	uint32_t n_cus = 0;
+	void *d_wavefront_ws = nullptr; // path state of the streaming mode (wavefront.hip)
+	size_t wavefront_ws_bytes = 0;
 	unsigned long long *d_debug_counters = nullptr; // walk diagnostics (DIAG builds, RMD_DEBUG=8|16)
 };
 

@@ -46,6 +46,10 @@ hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const 
                                const WaveTile *wave_tiles, double *accum);
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub);
+// Streaming evaluation for scenes with grids (wavefront.hip).  Synchronises the stream while it polls for completion.
+size_t wavefront_workspace_bytes(uint32_t n_wave_tiles);
+hipError_t launch_wavefront(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const WaveTile *wave_tiles,
+                            double *accum, void *workspace, uint32_t n_cus);
 hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8, size_t n_pixels, double sample_count,
                           double exposure, double inv_gamma);
 hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in, int in_stride, double *out, int out_stride,
