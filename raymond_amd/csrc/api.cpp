@@ -384,6 +384,7 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 	}
 	if (k > sample_count / 8u) k = sample_count / 8u; // keep >= 8 samples per wave: path regeneration needs a run of samples
 	if (k > 64u) k = 64u;
+	while (k > 1u && (uint64_t)n_wave_tiles * k > 0x7FFFFFFFull) k--; // work items are indexed in 32 bits
 	return k < 2u ? 1u : k;
 }
 
@@ -403,7 +404,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	// Scenes with grids can also be evaluated by the streaming pipeline of wavefront.hip (RMD_GRID_MODE=wavefront):
 	// same result bit for bit, different schedule.
 	const char *mode = std::getenv("RMD_GRID_MODE");
-	if (scene->n_grids != 0 && mode && std::strcmp(mode, "wavefront") == 0 && !(P.debug_flags & 24u)) {
+	if (scene->n_grids != 0 && mode && std::strcmp(mode, "wavefront") == 0 && !(P.debug_flags & 24u) && (uint64_t)P.n_work * 64u < 0x7FFFFFFFull) {
 		const size_t need = rmd::wavefront_workspace_bytes(P.n_work);
 		if (need > ctx->wavefront_ws_bytes) {
 			if (ctx->d_wavefront_ws) RMD_HIP(ctx, hipFree(ctx->d_wavefront_ws));
