@@ -245,7 +245,8 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		}
 		d.n_cells = g.n_cells, d.n_tris = g.n_tris;
 		// the kernel keeps the reference's linear cell index x + res.x*(y + z*res.z) in 32 bits
-		if ((uint64_t)g.resolution[0] * ((uint64_t)g.resolution[1] + (uint64_t)g.resolution[2] * g.resolution[2]) >= (1ull << 31)) {
+		if ((uint64_t)g.resolution[0] * ((uint64_t)g.resolution[1] + (uint64_t)g.resolution[2] * g.resolution[2]) >= (1ull << 31) ||
+		    g.n_cells > (1ull << 31)) {
 			rmd_scene_destroy(sc);
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: grid resolution too large for 31-bit cell indices");
 		}

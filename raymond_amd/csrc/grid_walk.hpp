@@ -51,30 +51,26 @@ RMD_DEV TriRecord load_record(const RMD_GLOBAL unsigned char *p) {
 	return r;
 }
 
-// One DDA step (acc_grid.rs:155-183), branch-free: the same three comparisons select the axis
-// (x if tmx<tmy && tmx<tmz; y if !(tmx<tmy) && tmy<tmz; else z), the cell moves, and that axis' t_max advances
-// (its value is irrelevant once the ray has left the grid).  `idx` is the reference's linear cell index
-// x + res.x*(y + z*res.z) (Q5: res.z where res.y is meant) kept incrementally: a step along x/y/z adds dix/diy/diz.
-// 32-bit arithmetic is exact because the upload rejects grids whose largest reachable index does not fit 31 bits.
-// Outputs the stepped state in n*; returns false when the ray leaves the grid (:158,:164,:172,:178).
-RMD_DEV bool dda_step(int32_t cx, int32_t cy, int32_t cz, uint32_t idx, double tmx, double tmy, double tmz, int32_t sx, int32_t sy,
-                      int32_t sz, int32_t dix, int32_t diy, int32_t diz, double tdx, double tdy, double tdz, int32_t rx, int32_t ry,
-                      int32_t rz, int32_t &ncx, int32_t &ncy, int32_t &ncz, uint32_t &nidx, double &ntmx, double &ntmy, double &ntmz) {
-	const bool lt_xy = tmx < tmy, lt_xz = tmx < tmz, lt_yz = tmy < tmz;
-	const bool ax = lt_xy && lt_xz;
-	const bool ay = !lt_xy && lt_yz;
-	const bool az = !ax && !ay;
-	const int32_t c_new = ax ? cx + sx : (ay ? cy + sy : cz + sz);
-	const int32_t r_sel = ax ? rx : (ay ? ry : rz);
-	ncx = ax ? c_new : cx;
-	ncy = ay ? c_new : cy;
-	ncz = az ? c_new : cz;
-	nidx = idx + (uint32_t)(ax ? dix : (ay ? diy : diz));
-	const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
-	ntmx = ax ? nx : tmx;
-	ntmy = ay ? ny : tmy;
-	ntmz = az ? nz : tmz;
-	return (uint32_t)c_new < (uint32_t)r_sel; // 0 <= c_new < res
+// One DDA step (acc_grid.rs:155-183) is done inline in the walk loop below.  The same three comparisons select the axis
+// (x if tmx<tmy && tmx<tmz; y if !(tmx<tmy) && tmy<tmz; else z); that axis' t_max advances by its t_delta (same
+// additions in the same order as the reference) and the cell moves.  The cell itself is not kept: what the walk needs is
+//   * `idx`, the reference's linear cell index x + res.x*(y + z*res.z) (Q5: res.z where res.y is meant), updated
+//     incrementally — a step along x/y/z adds dix/diy/diz (32-bit arithmetic is exact: the upload rejects grids whose
+//     largest reachable index does not fit 31 bits);
+//   * `rem[a]`, the number of steps along axis a after which the reference's range test (:158,:164,:172,:178:
+//     `cell.a < 0 || cell.a >= res.a` → None) fails; a step decrements its axis' counter and the ray has left the
+//     grid when a counter reaches 0.
+// steps_to_exit() derives the counter from the start cell exactly as those tests would fire, including start cells
+// that are themselves out of range on an axis (the reference only tests an axis when it steps along it).
+RMD_DEV uint32_t steps_to_exit(int32_t c, int32_t s, int32_t r) {
+	if (s > 0) {
+		if (c <= -2) return 1u; // c+1 is still negative
+		const int64_t k = (int64_t)r - (int64_t)c;
+		return k < 1 ? 1u : (uint32_t)k;
+	}
+	if (c > r) return 1u; // c-1 is still >= r
+	const int64_t k = (int64_t)c + 1;
+	return k < 1 ? 1u : (uint32_t)k;
 }
 
 // Candidates a lane may collect per round (speculative look-ahead along its own DDA path).
@@ -100,17 +96,19 @@ struct WalkScratch {
 };
 
 // Must be called by all 64 lanes of the wave in uniform control flow; `want` selects the lanes that have a ray.
-// lds_mask: occupancy bits of this grid in LDS (bit i covers cells [i << shift, (i+1) << shift)), or nullptr.
+// lds_mask: occupancy bits of this grid in LDS (bit i covers cells [i << shift, (i+1) << shift)).
 // scr: this wave's scratch in LDS.
 RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, WalkScratch &scr, bool want, V3 ro, V3 rd, bool &hit_out,
                                  double &t_out, uint32_t &tri_out, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
 	const uint64_t resx = g.res[0], resz = g.res[2], n_cells = g.n_cells;
-	const uint32_t mask_bits = g.mask_bits, mask_shift = g.mask_shift;
+	const uint32_t mask_shift = g.mask_shift;
 	const uint32_t mask_pad_bit = g.mask_n_words * 32u - 32u; // first bit of the all-zero word that ends every mask (api.cpp)
-	// with res.z <= res.y no in-range cell can index past the cell array (Q5), so the per-step test is dropped
-	const bool idx_can_leave_array = (resx - 1u) + resx * ((g.res[1] - 1u) + (resz - 1u) * resz) >= n_cells;
+	// Every cell index is tested against the cell array (:129-131) — with Q5, or a start cell beyond the grid on an axis
+	// that is never stepped, an index can pass the array while all range tests hold.  n_cells <= 2^31 and one step moves
+	// the index by less than 2^31, so the wrapped 32-bit index is out of range exactly when the reference's usize one is.
+	const uint32_t idx_limit = (uint32_t)n_cells;
 	const RMD_GLOBAL CellEntry *entries = as_global(g.cell_entries);
 	const RMD_GLOBAL unsigned char *runs = as_global(reinterpret_cast<const unsigned char *>(g.tri_runs));
 #if RMD_DIAG
@@ -129,14 +127,15 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 #endif
 
 	bool walking = false;
-	int32_t cx = 0, cy = 0, cz = 0, sx = 1, sy = 1, sz = 1, dix = 0, diy = 0, diz = 0;
-	uint32_t idx = 0;
+	int32_t dix = 0, diy = 0, diz = 0;
+	uint32_t idx = 0, remx = 1, remy = 1, remz = 1;
 	double tmx = 0.0, tmy = 0.0, tmz = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
 	if (want && !(debug_flags & 2u)) {
 		// acc_grid.rs:90-125
 		V3 bmin = ld3(g.bbox_min);
 		double t_outer;
 		if (aabb_intersect(bmin, ld3(g.bbox_max), ro, rd, t_outer)) {
+			int32_t cx = 0, cy = 0, cz = 0;
 			V3 cs = ld3(g.cell_size);
 			V3 start = ro - bmin;
 			bool ok = cast_i32(start.x / cs.x, cx) && cast_i32(start.y / cs.y, cy) && cast_i32(start.z / cs.z, cz);
@@ -153,8 +152,9 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				idx = (uint32_t)idx0;
 			}
 			if (ok) {
-				sx = signbit(rd.x) ? -1 : 1, sy = signbit(rd.y) ? -1 : 1, sz = signbit(rd.z) ? -1 : 1;
+				const int32_t sx = signbit(rd.x) ? -1 : 1, sy = signbit(rd.y) ? -1 : 1, sz = signbit(rd.z) ? -1 : 1;
 				dix = sx, diy = sy * (int32_t)resx, diz = sz * (int32_t)(resx * resz);
+				remx = steps_to_exit(cx, sx, rx), remy = steps_to_exit(cy, sy, ry), remz = steps_to_exit(cz, sz, rz);
 				tdx = (rd.x < 0.0 ? -cs.x : cs.x) / rd.x;
 				tdy = (rd.y < 0.0 ? -cs.y : cs.y) / rd.y;
 				tdz = (rd.z < 0.0 ? -cs.z : cs.z) / rd.z;
@@ -184,9 +184,8 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		//    adjacent non-empty cells of a surface crossing; if an earlier candidate does hit, the later ones are simply
 		//    ignored below.  Every cell the lane stands on has a valid index (< n_cells: checked for the first cell
 		//    above and after every step, acc_grid.rs:129-131).  The step is computed while the mask word is in flight.
-		uint32_t cand_idx[kWalkCand];
-#pragma unroll
-		for (uint32_t m = 0; m < kWalkCand; m++) cand_idx[m] = 0;
+		// Candidates are parked in this lane's column of scr.first (slot m at [m * 64 + lane]) — the array is only
+		// (re)written for the tests after every lane has read its candidates back, in program order within the wave.
 		// `budget` = steps this lane may still take in this round: unlimited until its first candidate, kWalkLookahead
 		// after it, 0 once kWalkCand candidates are recorded.
 		uint32_t n_cand = 0, budget = 0x7FFFFFFFu;
@@ -194,28 +193,28 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		while (walking && budget != 0u) {
 			if (count_events) { unsigned long long am = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(am)) { atomicAdd(&dbg[4], 1ull); atomicAdd(&dbg[5], (unsigned long long)__popcll(am)); } }
 			// occupancy bit of the current cell: indices past the mask read the zero word that pads it
-			uint32_t word = 0xFFFFFFFFu, bit = 0;
-			if (lds_mask) {
-				bit = idx >> mask_shift;
-				bit = bit < mask_bits ? bit : mask_pad_bit;
-				word = lds_mask[bit >> 5];
+			uint32_t bit = idx >> mask_shift;
+			bit = bit < mask_pad_bit ? bit : mask_pad_bit;
+			const uint32_t word = lds_mask[bit >> 5];
+			const uint32_t here = idx;
+			// the step (see above), computed while the mask word is in flight
+			const bool lt_xy = tmx < tmy, lt_xz = tmx < tmz, lt_yz = tmy < tmz;
+			if (lt_xy && lt_xz) {
+				tmx += tdx, remx--, idx += (uint32_t)dix;
+			} else if (!lt_xy && lt_yz) {
+				tmy += tdy, remy--, idx += (uint32_t)diy;
+			} else {
+				tmz += tdz, remz--, idx += (uint32_t)diz;
 			}
-			int32_t ncx, ncy, ncz;
-			uint32_t nidx;
-			double ntmx, ntmy, ntmz;
-			bool inside = dda_step(cx, cy, cz, idx, tmx, tmy, tmz, sx, sy, sz, dix, diy, diz, tdx, tdy, tdz, rx, ry, rz, ncx, ncy, ncz, nidx, ntmx, ntmy, ntmz);
-			if (idx_can_leave_array) inside = inside && nidx < (uint32_t)n_cells; // next cell past the cell array: the walk returns None there
-			const bool candidate = (word >> (bit & 31u)) & 1u;
+			const uint32_t rem_min = remx < remy ? (remx < remz ? remx : remz) : (remy < remz ? remy : remz);
+			// left the grid (a range test fired), or the next cell is past the cell array (:129-131): the walk returns None
+			walking = rem_min != 0u && idx < idx_limit;
 			budget--;
-			if (candidate) {
-#pragma unroll
-				for (uint32_t m = 0; m < kWalkCand; m++)
-					if (n_cand == m) cand_idx[m] = idx;
+			if ((word >> (bit & 31u)) & 1u) {
+				scr.first[n_cand * 64u + lane] = here;
 				n_cand++;
 				budget = n_cand == kWalkCand ? 0u : (budget < kWalkLookahead ? budget : kWalkLookahead);
 			}
-			cx = ncx, cy = ncy, cz = ncz, idx = nidx, tmx = ntmx, tmy = ntmy, tmz = ntmz;
-			walking = inside;
 		}
 		RMD_STAMP(1)
 		if (__ballot(n_cand != 0u) == 0ull) {
@@ -225,13 +224,17 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 
 		// 2. the candidates' cell entries {first record, count}: all gathers of the round in flight together
 		uint32_t c_first[kWalkCand], c_count[kWalkCand];
+		{
+			// unconditional gathers (an unused slot reads cell 0) so that the kWalkCand loads overlap; masked afterwards
+			uint32_t ci[kWalkCand];
 #pragma unroll
-		for (uint32_t m = 0; m < kWalkCand; m++) {
-			// unconditional gather (an unused slot reads cell 0) so that the kWalkCand loads overlap; masked afterwards
-			const uint32_t ci = m < n_cand ? cand_idx[m] : 0u;
-			const uint32_t e_first = entries[ci].first, e_count = entries[ci].count;
-			c_first[m] = e_first;
-			c_count[m] = (m < n_cand && !(debug_flags & 1u)) ? e_count : 0u;
+			for (uint32_t m = 0; m < kWalkCand; m++) ci[m] = scr.first[m * 64u + lane];
+#pragma unroll
+			for (uint32_t m = 0; m < kWalkCand; m++) ci[m] = m < n_cand ? ci[m] : 0u;
+#pragma unroll
+			for (uint32_t m = 0; m < kWalkCand; m++) c_first[m] = entries[ci[m]].first, c_count[m] = entries[ci[m]].count;
+#pragma unroll
+			for (uint32_t m = 0; m < kWalkCand; m++) c_count[m] = (m < n_cand && !(debug_flags & 1u)) ? c_count[m] : 0u;
 		}
 		RMD_STAMP(2)
 
