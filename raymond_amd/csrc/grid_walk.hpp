@@ -38,6 +38,33 @@ RMD_DEV double bperm_f64(int addr, double v) {
 	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// Inclusive scans over the 64 lanes of the wave in 6 DPP steps (row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3) — VALU only, no LDS round trips.  Lanes for which a
+// step has no source keep the identity 0.  Must be executed by all 64 lanes.
+template <int CTRL, int ROW_MASK>
+RMD_DEV uint32_t dpp_from(uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+RMD_DEV uint32_t wave_scan_add(uint32_t v) {
+	v += dpp_from<0x111, 0xf>(v);
+	v += dpp_from<0x112, 0xf>(v);
+	v += dpp_from<0x114, 0xf>(v);
+	v += dpp_from<0x118, 0xf>(v);
+	v += dpp_from<0x142, 0xa>(v);
+	v += dpp_from<0x143, 0xc>(v);
+	return v;
+}
+RMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+RMD_DEV uint32_t wave_scan_max(uint32_t v) {
+	v = umax(v, dpp_from<0x111, 0xf>(v));
+	v = umax(v, dpp_from<0x112, 0xf>(v));
+	v = umax(v, dpp_from<0x114, 0xf>(v));
+	v = umax(v, dpp_from<0x118, 0xf>(v));
+	v = umax(v, dpp_from<0x142, 0xa>(v));
+	v = umax(v, dpp_from<0x143, 0xc>(v));
+	return v;
+}
+
 // One 80-byte triangle record of a cell run: v0, edge1, edge2, original triangle index.
 struct TriRecord {
 	V3 v0, e1, e2;
@@ -78,8 +105,6 @@ RMD_DEV uint32_t steps_to_exit(int32_t c, int32_t s, int32_t r) {
 #define RMD_WALK_CANDIDATES 4
 #endif
 constexpr uint32_t kWalkCand = RMD_WALK_CANDIDATES;
-// first probe distance of the binary search over the (at most 64 * kWalkCand) pairs of a round: half the next power of two
-constexpr uint32_t kPairSearchStart = kWalkCand <= 1 ? 32u : (kWalkCand <= 2 ? 64u : (kWalkCand <= 4 ? 128u : 256u));
 static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 // After its first candidate a lane keeps stepping at most this many cells looking for more (the non-empty cells of
 // one surface crossing are adjacent); further cells wait for the next round.
@@ -88,11 +113,11 @@ static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 #endif
 constexpr uint32_t kWalkLookahead = RMD_WALK_LOOKAHEAD;
 
-// Per-wave LDS scratch of the cooperative triangle tests: one entry per (lane, candidate) pair of the round, by rank.
-struct WalkScratch {
-	uint32_t start[64 * kWalkCand]; // exclusive prefix sum of the pairs' triangle counts
-	uint32_t first[64 * kWalkCand]; // first record of the pair's cell run
-	uint32_t owner[64 * kWalkCand]; // lane | candidate slot << 8
+// Per-wave LDS scratch of the cooperative triangle tests.  A (lane, candidate slot) pair has the key lane * kWalkCand + slot.
+struct alignas(16) WalkScratch {
+	uint32_t start[64 * kWalkCand]; // by key: number of the pair's first test in the round (exclusive prefix sum of the counts)
+	uint32_t first[64 * kWalkCand]; // by key: first record of the pair's cell run; during the walk, slot m of lane l is parked at [m * 64 + l]
+	uint32_t marker[64];            // per 64-test chunk: lane + 1 of the lane whose tests begin at that position
 };
 
 // Must be called by all 64 lanes of the wave in uniform control flow; `want` selects the lanes that have a ray.
@@ -232,7 +257,10 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 #pragma unroll
 			for (uint32_t m = 0; m < kWalkCand; m++) ci[m] = m < n_cand ? ci[m] : 0u;
 #pragma unroll
-			for (uint32_t m = 0; m < kWalkCand; m++) c_first[m] = entries[ci[m]].first, c_count[m] = entries[ci[m]].count;
+			for (uint32_t m = 0; m < kWalkCand; m++) { // one 8-byte load per entry: {first, count}
+				const unsigned long long e = reinterpret_cast<const RMD_GLOBAL unsigned long long *>(entries)[ci[m]];
+				c_first[m] = (uint32_t)e, c_count[m] = (uint32_t)(e >> 32);
+			}
 #pragma unroll
 			for (uint32_t m = 0; m < kWalkCand; m++) c_count[m] = (m < n_cand && !(debug_flags & 1u)) ? c_count[m] : 0u;
 		}
@@ -247,54 +275,63 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		//    lane order = ascending (lane, candidate, triangle) order with a strict '<': within a candidate cell that is
 		//    the reference's sequential scan (acc_grid.rs:135-149: closest starts at 5712515.0, first wins ties), and
 		//    across candidates the earliest cell with an accepted hit wins (:151-153).
-		uint32_t my_pairs = 0, my_tests = 0;
+		// 3. triangle tests, distributed over the whole wave.  Lane l's candidates own c_count[0..] tests each; an exclusive
+		//    prefix sum over the lanes numbers all tests of the round 0..T-1 in (lane, candidate, triangle) order and the wave
+		//    takes them 64 at a time.  For a chunk, every lane whose tests overlap it drops lane+1 at the position where its
+		//    tests begin inside the chunk (LDS), a max-scan carries that to the following positions, and each test then finds
+		//    its candidate slot by comparing against the owner's pair starts (one 16-byte LDS read).  It fetches that pair's
+		//    ray from its owner lane's registers (ds_bpermute) and the triangle record from the cell's contiguous run
+		//    (neighbouring lanes read neighbouring 80-byte records: coalesced).  Hits are rare; they are applied by a scalar
+		//    loop over the hit ballot in ascending lane order = ascending (lane, candidate, triangle) order with a strict '<':
+		//    within a candidate cell that is the reference's sequential scan (acc_grid.rs:135-149: closest starts at
+		//    5712515.0, first wins ties), and across candidates the earliest cell with an accepted hit wins (:151-153).
+		uint32_t my_tests = 0;
 #pragma unroll
-		for (uint32_t m = 0; m < kWalkCand; m++) my_pairs += c_count[m] ? 1u : 0u, my_tests += c_count[m];
-		uint32_t incl_t = my_tests, incl_p = my_pairs; // inclusive scans over the lanes (Hillis-Steele through the LDS crossbar)
-#pragma unroll
-		for (int dd = 1; dd < 64; dd <<= 1) {
-			const uint32_t up_t = (uint32_t)__shfl_up((int)incl_t, dd, 64), up_p = (uint32_t)__shfl_up((int)incl_p, dd, 64);
-			if ((int)lane >= dd) incl_t += up_t, incl_p += up_p;
-		}
-		const uint32_t total = readlane_u32(incl_t, 63), n_pairs = readlane_u32(incl_p, 63);
-		if (count_events && lane == 0) atomicAdd(&dbg[6], 1ull), atomicAdd(&dbg[7], (unsigned long long)n_pairs), atomicAdd(&dbg[8], (unsigned long long)total), atomicAdd(&dbg[9], (unsigned long long)((total + 63u) / 64u));
+		for (uint32_t m = 0; m < kWalkCand; m++) my_tests += c_count[m];
+		const uint32_t incl_t = wave_scan_add(my_tests);
+		const uint32_t total = readlane_u32(incl_t, 63);
+		const uint32_t my_begin = incl_t - my_tests, my_end = incl_t;
+		if (count_events && lane == 0) atomicAdd(&dbg[6], 1ull), atomicAdd(&dbg[8], (unsigned long long)total), atomicAdd(&dbg[9], (unsigned long long)((total + 63u) / 64u));
 		bool any = false;
 		uint32_t any_slot = 0, closest_tri = 0;
 		double closest = 5712515.0;
 		if (total != 0u) {
 			{
-				uint32_t rank = incl_p - my_pairs, run = incl_t - my_tests;
+				uint32_t run = my_begin;
 #pragma unroll
-				for (uint32_t m = 0; m < kWalkCand; m++)
-					if (c_count[m]) {
-						scr.start[rank] = run, scr.first[rank] = c_first[m], scr.owner[rank] = lane | (m << 8);
-						rank++, run += c_count[m];
-					}
+				for (uint32_t m = 0; m < kWalkCand; m++) {
+					scr.start[lane * kWalkCand + m] = run, scr.first[lane * kWalkCand + m] = c_first[m];
+					run += c_count[m];
+				}
 			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			RMD_STAMP(3)
 			for (uint32_t base = 0; base < total; base += 64u) {
 				const uint32_t w = base + lane;
+				scr.marker[lane] = 0u;
+				if (my_tests != 0u && my_begin < base + 64u && my_end > base) scr.marker[umax(my_begin, base) - base] = lane + 1u;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const uint32_t owner_lane = wave_scan_max(scr.marker[lane]) - 1u; // position 0 is always marked
 				bool h = false;
 				double t = 0.0;
-				uint32_t tri = 0, own = 0;
-				uint32_t k = 0;
+				uint32_t tri = 0, own = 0, rec_index = 0;
 				if (w < total) {
+					uint32_t slot = 0, slot_start = scr.start[owner_lane * kWalkCand];
 #pragma unroll
-					for (uint32_t step = kPairSearchStart; step > 0u; step >>= 1) { // powers of two: every rank is reachable
-						const uint32_t mid = k + step;
-						if (mid < n_pairs && scr.start[mid] <= w) k = mid;
+					for (uint32_t m = 1; m < kWalkCand; m++) {
+						const uint32_t sm = scr.start[owner_lane * kWalkCand + m];
+						if (sm <= w) slot = m, slot_start = sm; // an empty slot shares its start with the next one: the last match is the non-empty pair
 					}
-					own = scr.owner[k];
+					own = owner_lane | (slot << 8);
+					rec_index = scr.first[owner_lane * kWalkCand + slot] + (w - slot_start);
 				}
 				// the owner lane's ray, straight from its registers (every lane takes part in the permute)
 				const int src = (int)((own & 63u) << 2);
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				if (w < total) {
-					const RMD_GLOBAL unsigned char *rec = runs + (size_t)(scr.first[k] + (w - scr.start[k])) * 80u;
+					const RMD_GLOBAL unsigned char *rec = runs + (size_t)rec_index * 80u;
 					const TriRecord r = load_record(rec);
 					tri = r.tri;
 					h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t);
