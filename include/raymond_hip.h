@@ -59,7 +59,10 @@ enum { RMD_MAT_DIFFUSE = 0, RMD_MAT_METAL = 1, RMD_MAT_EMISSION = 2 };
 
 /* Material::Diffuse(color, roughness) | Metal(color, roughness) | Emission(e, v2, f1, f2).
  * For Emission `color` carries the first vector (the only field trace() reads,
- * src/trace.rs:250-252); v2/f1/f2 ride along untouched in `emission_aux`. */
+ * src/trace.rs:250-252); v2/f1/f2 ride along untouched in `emission_aux`.
+ * |roughness| must be <= 512 for Diffuse/Metal (rmd_scene_create returns RMD_ERR_UNSUPPORTED
+ * otherwise): the GGX sampling angle roughness^2 * sqrt(u / (1 - u)) is reduced on the device
+ * by a method that is accurate below 2^45. */
 typedef struct rmd_material {
 	uint32_t kind;
 	uint32_t _pad;

@@ -191,6 +191,9 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		d.geometry_kind = o.geometry_kind, d.grid_index = o.grid_index, d.material_kind = o.material.kind;
 		for (int a = 0; a < 3; a++) d.origin[a] = o.origin[a], d.normal[a] = o.normal[a], d.color[a] = o.material.color[a];
 		d.radius = o.radius;
+		// the GGX angle roughness^2 * sqrt(u / (1 - u)) must stay inside sincos_cw's reduction range (device_core.hpp)
+		if (o.material.kind != RMD_MAT_EMISSION && std::fabs(o.material.roughness) > rmd::kMaxRoughness)
+			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: |roughness| > 512 is not supported");
 		d.roughness = o.material.roughness;
 		d.metalness = o.material.kind == RMD_MAT_METAL ? 1.0 : 0.0; // src/trace.rs:248-249
 	}
@@ -455,8 +458,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			std::fprintf(stderr, "[rmd stamps, cycles] init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
 			             h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
 		else
-			std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu pairs=%llu tests=%llu chunks=%llu\n",
-			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+			std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu tests=%llu chunks=%llu | main_iterations=%llu live_lanes=%llu lanes_with_ray=%llu\n",
+			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12]);
 	}
 	return RMD_OK;
 }

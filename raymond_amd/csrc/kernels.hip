@@ -173,6 +173,12 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			if (P.bounce_limit == 0u) terminal = true; // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237)
 		}
 		const bool want = alive && !terminal;
+#if RMD_DIAG
+		if ((P.debug_flags & 8u) && P.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
+			const unsigned long long am = __ballot(alive), wm = __ballot(want);
+			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm));
+		}
+#endif
 		// src/trace.rs:239
 		double t;
 		uint32_t sub;

@@ -34,6 +34,8 @@ enum ProbeOp {
 constexpr size_t kLdsBudgetBytes = 160u * 1024u;
 // LDS bytes reserved for the grids' occupancy masks (shared by the waves of a workgroup)
 constexpr size_t kMaskBudgetBytes = 48u * 1024u;
+// largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
+constexpr double kMaxRoughness = 512.0;
 // waves per workgroup of the grid instantiation (they share the LDS occupancy masks)
 // 4-wave workgroups: 4 of them (16 waves) fit a CU's LDS beside their staged masks and retire at a finer grain than 8-wave ones
 #ifndef RMD_GRID_WAVES

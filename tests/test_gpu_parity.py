@@ -5,9 +5,10 @@ per-sample radiance + hit sequence -> config-1 image -> size-independent propert
 (pass splitting, tile sharding, accumulate semantics).
 
 Tolerances (binary64 everywhere; +,-,*,/,sqrt are correctly rounded on both sides and no FMA contraction is
-allowed.  The sides differ in libm — glibc vs ROCm ocml for sin/cos/acos — in x^5 of the Schlick term (libm pow vs
-three multiplications) and in the association of the bounce weights, which the kernel multiplies forward into a
-throughput instead of applying them on the way back up the recursion):
+allowed.  The sides differ in the elementary functions — glibc sin/cos/acos on the oracle's side; on the device a
+Cody-Waite + fdlibm-kernel sin/cos (<= 1.6 ulp) and sin/cos(acos(s)) taken as sqrt((1-s)(1+s)) / s — in x^5 of the
+Schlick term (libm pow vs three multiplications) and in the association of the bounce weights, which the kernel
+multiplies forward into a throughput instead of applying them on the way back up the recursion):
   * RNG, integer outputs, hit/miss flags, object/triangle ids: bit-exact;
   * arithmetic-only device functions (intersections, ONB, normals): <= 4 ulp, in practice 0;
   * libm-bound device functions: relative 1e-13;
@@ -438,6 +439,14 @@ def test_error_paths(gpu_ctx):
     assert e.value.status == abi.RMD_ERR_INVALID_ARGUMENT
     assert b"outside" in gpu_ctx.L.rmd_last_error(gpu_ctx.handle)
     fb.close(), ds.close()
+    # a roughness whose GGX angle could leave the device sin/cos' reduction range is refused at upload
+    from raymond_amd.scene import Material, Object, Scene, Sphere
+
+    wild = Scene()
+    wild.objects.append(Object(Sphere((0.0, 0.0, 3.0), 1.0), Material.Metal((1.0, 1.0, 1.0), 1000.0)))
+    with pytest.raises(lib.RaymondError) as e:
+        render.DeviceScene(gpu_ctx, wild)
+    assert e.value.status == abi.RMD_ERR_UNSUPPORTED
 
 
 def test_sample_split_is_bit_exact(gpu_ctx, small_mesh_scene):
