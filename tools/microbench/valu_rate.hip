@@ -1,0 +1,62 @@
+// Issue-rate probe for a few VALU opcodes on gfx950: each wave runs N iterations of 8 independent chains of one opcode.
+// Build + run:  hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate tools/microbench/valu_rate.hip && /tmp/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define CHAINS 8
+template <int OP>
+__global__ __launch_bounds__(256) void k(uint32_t *out, int n, uint32_t seed) {
+	uint32_t a[CHAINS];
+	double d[CHAINS];
+	for (int i = 0; i < CHAINS; i++) a[i] = seed + threadIdx.x * 977u + i, d[i] = 1.0 + 1e-9 * a[i];
+	for (int it = 0; it < n; it++) {
+#pragma unroll
+		for (int i = 0; i < CHAINS; i++) {
+			if (OP == 0) a[i] = a[i] + 0x9E3779B9u ^ (a[i] >> 3);           // add+xor+shift baseline (3 ops)
+			if (OP == 1) a[i] = a[i] * 0xD2511F53u;                           // v_mul_lo_u32
+			if (OP == 2) a[i] = __umulhi(a[i], 0xD2511F53u) + 1u;             // v_mul_hi_u32 (+add)
+			if (OP == 3) { uint64_t p = (uint64_t)a[i] * 0xD2511F53u; a[i] = (uint32_t)p ^ (uint32_t)(p >> 32); } // mad_u64_u32 (+xor)
+			if (OP == 4) d[i] = d[i] * 1.0000001;                             // v_mul_f64
+			if (OP == 5) d[i] = __builtin_fma(d[i], 1.0000001, 1e-12);        // v_fma_f64
+			if (OP == 6) d[i] = d[i] + 1e-7;                                  // v_add_f64
+			if (OP == 7) d[i] = __builtin_amdgcn_rcp(d[i]) + 1.0;             // v_rcp_f64 (+add)
+			if (OP == 8) d[i] = __builtin_amdgcn_rsq(d[i]) + 1.0;             // v_rsq_f64 (+add)
+		}
+	}
+	uint32_t r = 0;
+	for (int i = 0; i < CHAINS; i++) r ^= a[i] ^ (uint32_t)(long long)d[i];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int OP>
+void run(const char *name, int ops_per_step) {
+	uint32_t *out;
+	const int blocks = 256 * 8, n = 4096;
+	hipMalloc(&out, blocks * 256 * 4);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0), hipEventCreate(&e1);
+	k<OP><<<blocks, 256>>>(out, 16, 1);
+	hipDeviceSynchronize();
+	hipEventRecord(e0);
+	k<OP><<<blocks, 256>>>(out, n, 1);
+	hipEventRecord(e1);
+	hipEventSynchronize(e1);
+	float ms;
+	hipEventElapsedTime(&ms, e0, e1);
+	double wave_instr = (double)blocks * 4 * n * CHAINS; // wave-level chain steps
+	// per SIMD: 256 CUs * 4 SIMDs
+	double per_simd = wave_instr / (256.0 * 4.0);
+	printf("%-28s %8.3f ms  -> %.2f ns per wave-step per SIMD  (%d op(s) per step)\n", name, ms, ms * 1e6 / per_simd, ops_per_step);
+	hipFree(out);
+}
+int main() {
+	run<0>("add+xor+shift (3 int ops)", 3);
+	run<1>("v_mul_lo_u32", 1);
+	run<2>("v_mul_hi_u32 + add", 2);
+	run<3>("mad_u64_u32 + xor", 2);
+	run<4>("v_mul_f64", 1);
+	run<5>("v_fma_f64", 1);
+	run<6>("v_add_f64", 1);
+	run<7>("v_rcp_f64 + add", 2);
+	run<8>("v_rsq_f64 + add", 2);
+	return 0;
+}
