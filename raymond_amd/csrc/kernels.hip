@@ -209,13 +209,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 						normal = mk(0.0, 0.0, 0.0); // unreachable: a scene with grid objects runs the GRID instantiation
 					}
 					Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
-					// trace() returns  diffuse (:281-282)  ((A (.) radiance) * cos) / (prob_d * pdf)
-					//                  specular (:315-318) (((A (.) radiance) * cos) / (1 - prob_d)) / pdf
-					// i.e. radiance times a per-channel weight known before the recursive call.  The weights are multiplied
-					// forward into T instead of being applied on the way back up (same factors, different association:
-					// a few ulp per bounce, far inside the 1e-9 per-sample bar).
-					V3 wgt = (b.A * b.cosv) / b.d1;
-					if (b.specular) wgt = wgt / b.d2;
+					const V3 wgt = bounce_weight(b); // same factors as :281-282 / :315-318, multiplied forward
 					T = hadamard(T, wgt);
 					ro = b.next_origin, rd = b.next_dir;
 					depth++;

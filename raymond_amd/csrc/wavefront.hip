@@ -120,8 +120,7 @@ __global__ __launch_bounds__(256) void wf_step(RenderParams P, WfState st, const
 					normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, frag);
 				}
 				Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
-				V3 wgt = (b.A * b.cosv) / b.d1;
-				if (b.specular) wgt = wgt / b.d2;
+				const V3 wgt = bounce_weight(b);
 				T = hadamard(T, wgt);
 				ro = b.next_origin, rd = b.next_dir;
 				depth++;
