@@ -176,7 +176,8 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 #if RMD_DIAG
 		if ((P.debug_flags & 8u) && P.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
 			const unsigned long long am = __ballot(alive), wm = __ballot(want);
-			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm));
+			const unsigned long long fm = __ballot(alive && terminal); // samples that ended before the intersection (bounce limit 0 / failed DoF ray)
+			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm)), atomicAdd(&P.debug_counters[15], (unsigned long long)__popcll(fm));
 		}
 #endif
 		// src/trace.rs:239
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 					} else {
 						normal = mk(0.0, 0.0, 0.0); // unreachable: a scene with grid objects runs the GRID instantiation
 					}
+#if RMD_DIAG
+					if ((P.debug_flags & 8u) && P.debug_counters) { const unsigned long long sm = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(sm)) atomicAdd(&P.debug_counters[13], (unsigned long long)__popcll(sm)), atomicAdd(&P.debug_counters[14], 1ull); }
+#endif
 					Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
 					const V3 wgt = bounce_weight(b); // same factors as :281-282 / :315-318, multiplied forward
 					T = hadamard(T, wgt);
