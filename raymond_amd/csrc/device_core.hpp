@@ -34,7 +34,21 @@ RMD_DEV V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
 RMD_DEV V3 hadamard(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 RMD_DEV double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; } // cgmath: mul_element_wise().sum()
 RMD_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-RMD_DEV double length(V3 a) { return sqrt(dot(a, a)); }
+// IEEE square root.  The compiler's expansion of sqrt(double) pre-scales arguments below 2^-767 (compare, two selects,
+// two ldexp around the refinement); no length, discriminant or area on this path is ever that small, so when no lane of
+// the wave holds such an argument (one ballot) the same refinement runs without the scaling — identical operations on
+// identical values, hence identical results — and otherwise the wave takes the compiler's sequence.
+RMD_DEV double sqrt64(double x) {
+	if (__ballot(x < 0x1p-767 && x > 0.0) != 0ull) return __builtin_sqrt(x);
+	const double y = __builtin_amdgcn_rsq(x);
+	double g = x * y, h = y * 0.5;
+	const double r = __builtin_fma(-h, g, 0.5);
+	g = __builtin_fma(g, r, g), h = __builtin_fma(h, r, h);
+	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+	return __builtin_amdgcn_class(x, 0x260) ? x : g; // +-0 and +inf return themselves (class mask: -0 | +0 | +inf)
+}
+RMD_DEV double length(V3 a) { return sqrt64(dot(a, a)); }
 RMD_DEV V3 normalize(V3 a) { return a * (1.0 / length(a)); } // cgmath normalize_to(1.0)
 RMD_DEV double dist(V3 a, V3 b) { return length(b - a); }     // MetricSpace::distance
 
@@ -114,7 +128,7 @@ RMD_DEV bool sphere_intersect(V3 center, double radius, V3 ro, V3 rd, double &t_
 	double p = dot(q, q);
 	double r2 = radius * radius;
 	if (p > r2) return false;
-	t -= sqrt(r2 - p);
+	t -= sqrt64(r2 - p);
 	if (t <= 0.0) return false;
 	t_out = t;
 	return true;
@@ -169,7 +183,7 @@ RMD_DEV bool triangle_intersect(V3 v0, V3 edge1, V3 edge2, V3 ro, V3 rd, double 
 RMD_DEV double heron_area(V3 a, V3 b, V3 c) {
 	double ab = dist(a, b), ac = dist(a, c), bc = dist(b, c);
 	double s = (ab + ac + bc) / 2.0;
-	return sqrt(s * (s - ab) * (s - ac) * (s - bc));
+	return sqrt64(s * (s - ab) * (s - ac) * (s - bc));
 }
 template <class P>
 RMD_DEV V3 triangle_normal(P pos9, P nrm9, V3 position) {
@@ -260,12 +274,12 @@ RMD_DEV void sincos_cw(double x, double &s, double &c) {
 // (1.9e-16 vs 2.2e-16 relative) and within 3.1e-16 relative of it.
 RMD_DEV void hemisphere_sincos(double sr, double &st, double &ct) {
 	ct = sr;
-	st = sqrt((1.0 - sr) * (1.0 + sr));
+	st = sqrt64((1.0 - sr) * (1.0 + sr));
 }
 
 // :396-406
 RMD_DEV void cosine_hemisphere(double r1, double r2, V3 &dir, double &pdf) {
-	double sr = sqrt(r1);
+	double sr = sqrt64(r1);
 	double phi = 2.0 * kPi * r2;
 	pdf = sr;
 	double st, ct, sp, cp;
@@ -277,7 +291,7 @@ RMD_DEV void cosine_hemisphere(double r1, double r2, V3 &dir, double &pdf) {
 RMD_DEV V3 importance_sample_ggx(V3 reflect, double roughness, double r1, double r2) {
 	double a = roughness * roughness;
 	double phi = 2.0 * kPi * r1;
-	double theta = a * sqrt(r2 / (1.0 - r2));
+	double theta = a * sqrt64(r2 / (1.0 - r2));
 	double st, ct, sp, cp;
 	sincos_cw(theta, st, ct);
 	sincos_cw(phi, sp, cp);
@@ -325,7 +339,7 @@ RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double meta
 	V3 axis;
 	if (diffuse) {
 		// uniform_sample_hemisphere (:396-406), frame around the normal (:261-262)
-		const double sr = sqrt(r1);
+		const double sr = sqrt64(r1);
 		hemisphere_sincos(sr, st, ct);
 		phi = 2.0 * kPi * r2;
 		pdf_d = sr;
@@ -334,7 +348,7 @@ RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double meta
 		// importance_sample_ggx (:286-296), frame around the mirror direction (:285)
 		const double a = roughness * roughness;
 		phi = 2.0 * kPi * r1;
-		sincos_cw(a * sqrt(r2 / (1.0 - r2)), st, ct);
+		sincos_cw(a * sqrt64(r2 / (1.0 - r2)), st, ct);
 		axis = normalize(-view - 2.0 * (-dot(view, normal) * normal));
 	}
 	sincos_cw(phi, sp, cp);

@@ -357,6 +357,10 @@ __global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const dou
 		primary_ray(P, (uint32_t)a[0], (uint32_t)a[1], a[2], a[3], ro, rd);
 		o[0] = ro.x, o[1] = ro.y, o[2] = ro.z, o[3] = rd.x, o[4] = rd.y, o[5] = rd.z;
 	} break;
+	case PROBE_ELEMENTARY: { // the device's own sqrt / sin / cos (device_core.hpp)
+		o[0] = sqrt64(a[0]);
+		sincos_cw(a[0], o[1], o[2]);
+	} break;
 	default: break;
 	}
 }

@@ -27,6 +27,7 @@ enum ProbeOp {
 	PROBE_GEOMETRY_SMITH,
 	PROBE_FRESNEL_SCHLICK,
 	PROBE_PRIMARY_RAY,
+	PROBE_ELEMENTARY,
 	PROBE_OP_COUNT
 };
 

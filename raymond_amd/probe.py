@@ -25,6 +25,7 @@ _SIGS = {
     "rmd_probe_geometry_smith": [_vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "rmd_probe_fresnel_schlick": [_vp, _sz, _vp, _vp, _vp],
     "rmd_probe_primary_ray": [_vp, _sz, _P(abi.Camera), _vp, _vp, _vp],
+    "rmd_probe_elementary": [_vp, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_scene_intersect": [_vp, _vp, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_grid_intersect": [_vp, _vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_trace_samples": [_vp, _vp, _P(abi.Camera), _P(abi.Settings), _sz, _vp, _vp, _vp, _vp, _vp],
@@ -89,6 +90,15 @@ def uniform(ctx, seed, pixel, sample, draw):
     out = np.zeros(pixel.shape[0])
     ctx.check(L.rmd_probe_uniform(ctx.handle, seed, pixel.shape[0], _p(pixel), _p(sample), _p(draw), _p(out)))
     return out
+
+
+def elementary(ctx, x):
+    """-> (sqrt64(x), sin(x), cos(x)) as the device computes them"""
+    L = _L()
+    x = _f(x).ravel()
+    s, si, co = np.zeros_like(x), np.zeros_like(x), np.zeros_like(x)
+    ctx.check(L.rmd_probe_elementary(ctx.handle, x.shape[0], _p(x), _p(s), _p(si), _p(co)))
+    return s, si, co
 
 
 def primary_ray(ctx, cam, xy, u):

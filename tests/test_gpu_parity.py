@@ -190,6 +190,39 @@ def test_samplers_and_brdf_terms(gpu_ctx, oracle):
     assert rel_close(dF, oF, 1e-13).all()
 
 
+def test_device_sqrt_is_exact_and_sincos_within_2ulp(gpu_ctx):
+    """sqrt64 must be the IEEE square root on both of its paths (waves with and without arguments below 2^-767);
+    sincos_cw must stay within 2 ulp / 2.5e-16 of the true values over the arguments this path produces."""
+    rng = np.random.default_rng(21)
+    normal = np.ldexp(rng.uniform(0.5, 1.0, 2 * N), rng.integers(-700, 1000, 2 * N))  # whole waves on the fast path
+    mixed = np.ldexp(rng.uniform(0.5, 1.0, N), rng.integers(-1074, 1024, N))
+    mixed[:16] = [0.0, -0.0, np.inf, -np.inf, np.nan, -1.0, 5e-324, 2.0**-1022, 2.0**-767, np.nextafter(2.0**-767, 0), 1.0, 4.0, 2.0, 1e-300, 1e300, -5e-324]
+    x = np.concatenate([normal, mixed])
+    got, _, _ = probe.elementary(gpu_ctx, x)
+    with np.errstate(invalid="ignore"):
+        want = np.sqrt(x)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got[~nan].view(np.uint64), want[~nan].view(np.uint64))  # bit for bit, signed zeros included
+
+    u = rng.uniform(0, 1, N)
+    args = np.concatenate([
+        2.0 * np.pi * u,                                             # azimuth
+        rng.uniform(0, 1, N) * np.sqrt(u / (1.0 - u)),               # GGX angle, roughness^2 <= 1
+        np.ldexp(rng.uniform(0.5, 1.0, N), rng.integers(-60, 44, N)),  # anything below 2^44
+        np.arange(64) * (np.pi / 2),                                 # next to the quadrant boundaries
+        [0.0, 1.0 - 2.0**-53, 9.49e7, 2.0**27, 2.0**40],
+    ])
+    _, si, co = probe.elementary(gpu_ctx, args)
+    ref_s, ref_c = np.sin(args.astype(np.longdouble)), np.cos(args.astype(np.longdouble))
+    for got, ref in ((si, ref_s), (co, ref_c)):
+        err = np.abs(got.astype(np.longdouble) - ref).astype(np.float64)
+        ulp = np.spacing(np.abs(ref.astype(np.float64)))
+        # next to a zero of the function the 2-term reduction leaves ~k * 1.5e-33 absolute: compare absolutely there
+        assert np.all((err <= 2.0 * ulp) | (err <= 1e-18 * np.maximum(1.0, np.abs(args)))), float((err / ulp).max())
+        assert err.max() <= 2.5e-16
+
+
 def test_primary_ray(gpu_ctx, oracle):
     import ctypes as C
 
