@@ -1,6 +1,6 @@
 // HIP kernels of the radiance integrator for gfx950 (CDNA4).
 //
-// render_kernel<LIST=false, GRID> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel.
+// render_kernel<MODE=tiles|tiles-buffered, GRID> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel.
 //   Each lane runs the reference's per-pixel loop (src/trace.rs:197-205) for `sample_count` consecutive samples as an
 //   iterative state machine: a lane whose path ends regenerates the next sample's primary ray in place (in-lane path
 //   regeneration), so the wave stays full until the last samples.  trace()'s recursion (src/trace.rs:232-320) becomes a
@@ -9,7 +9,7 @@
 //   closest-hit loop reads it through scalar loads, the divergent post-hit lookup reads the LDS copy.  GRID = true adds
 //   the wave-cooperative grid walk (grid_walk.hpp) and shares the grids' occupancy masks through LDS.
 //   MFMA is not used: there is no dense contraction anywhere on this path.
-// render_kernel<LIST=true, GRID>  — the same code driven by an explicit (x, y, sample) list, one sample per lane,
+// render_kernel<MODE=list, GRID>  — the same code driven by an explicit (x, y, sample) list, one sample per lane,
 //   radiance written out per entry (per-sample parity probe).
 // probe_* — device-function known-answer probes for the parity tests.
 #include <hip/hip_runtime.h>
@@ -79,11 +79,17 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 #ifndef RMD_NOGRID_MINW
 #define RMD_NOGRID_MINW 3
 #endif
-template <bool LIST, bool GRID>
+// MODE: 0 = wave tiles, the lane keeps its pixel's sum (one wave per tile); 1 = wave tiles with the samples of a tile split
+// over several waves, every sample's radiance stored to the sample buffer for sum_kernel; 2 = explicit (x, y, sample) list.
+// (A template parameter rather than a launch parameter: the buffer mode then carries no accumulator and the direct mode no
+// buffer addressing — the grid kernel runs at its register limit.)
+enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
+template <int MODE, bool GRID>
 __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_MINW : RMD_NOGRID_MINW) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
                                                      const DevGrid *__restrict__ grids, const void *__restrict__ work,
                                                      double *__restrict__ out, int32_t *__restrict__ path_obj,
                                                      uint32_t *__restrict__ path_sub) {
+	constexpr bool LIST = MODE == kModeList;
 	extern __shared__ __align__(16) unsigned char smem[];
 	// LDS: [object table][grid occupancy masks][one walk scratch per wave]
 	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		// waves (neighbouring waves, same tile) that store every sample's radiance to the sample buffer; sum_kernel then
 		// adds them to the pixel in sample order, so the result is the same sequential sum as with one wave per tile
 		const uint32_t item = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
-		const uint32_t split = P.split_k > 1u ? P.split_k : 1u;
+		const uint32_t split = MODE == kModeTilesBuffered ? P.split_k : 1u;
 		const uint32_t wt = item / split, part = item % split;
 		bool have = wt < P.n_work;
 		WaveTile t = reinterpret_cast<const WaveTile *>(work)[have ? wt : 0];
@@ -133,13 +139,13 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		alive = have && lx < t.w && ly < t.h && s_hi > s_lo;
 		x = t.x0 + lx, y = t.y0 + ly;
 		s = P.sample_begin + s_lo, s_end = P.sample_begin + s_hi;
-		out_index = P.split_k > 1u ? ((size_t)wt * P.sample_count * 64u + lane) * 3 : ((size_t)x + (size_t)y * P.W) * 3;
+		out_index = MODE == kModeTilesBuffered ? ((size_t)wt * P.sample_count * 64u + lane) * 3 : ((size_t)x + (size_t)y * P.W) * 3;
 	}
 	const uint32_t pixel = y * P.W + x;
 	const bool writes = alive;
 
 	V3 acc = mk(0.0, 0.0, 0.0);
-	const bool to_buffer = !LIST && P.split_k > 1u;
+	constexpr bool to_buffer = MODE == kModeTilesBuffered;
 	if (!LIST && alive && !to_buffer) acc = ld3(out + out_index);
 
 	const V3 cam_pos = ld3(P.cam_pos);
@@ -422,17 +428,17 @@ uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total) {
 	return w;
 }
 
-template <bool LIST, bool GRID>
+template <int MODE, bool GRID>
 static hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
                                 uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub) {
 	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total);
 	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, wpw);
 	if (lds > 64u * 1024u) { // above the default dynamic-LDS limit: opt in on the current device (cheap, and correct per device)
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<LIST, GRID>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                   (int)kLdsBudgetBytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((render_kernel<LIST, GRID>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
+	hipLaunchKernelGGL((render_kernel<MODE, GRID>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
 	                   path_obj, path_sub);
 	return hipGetLastError();
 }
@@ -441,9 +447,13 @@ hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const 
                                const WaveTile *wave_tiles, double *accum) {
 	if (P.n_work == 0) return hipSuccess;
 	const uint32_t n_waves = P.n_work * (P.split_k > 1u ? P.split_k : 1u);
-	hipError_t e = P.n_grids ? launch_render<false, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
-	                         : launch_render<false, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
-	if (e != hipSuccess || P.split_k <= 1u) return e;
+	const bool buffered = P.split_k > 1u;
+	hipError_t e;
+	if (P.n_grids) e = buffered ? launch_render<kModeTilesBuffered, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
+	                            : launch_render<kModeTiles, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
+	else e = buffered ? launch_render<kModeTilesBuffered, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
+	                  : launch_render<kModeTiles, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
+	if (e != hipSuccess || !buffered) return e;
 	hipLaunchKernelGGL(sum_kernel, dim3(P.n_work), dim3(64), 0, stream, P, wave_tiles, (const double *)P.sample_buf, accum);
 	return hipGetLastError();
 }
@@ -452,8 +462,8 @@ hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const D
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub) {
 	if (P.n_work == 0) return hipSuccess;
 	const uint32_t n_waves = (P.n_work + 63u) / 64u;
-	if (P.n_grids) return launch_render<true, true>(stream, P, objs, grids, list, n_waves, rgb_out, path_obj, path_sub);
-	return launch_render<true, false>(stream, P, objs, grids, list, n_waves, rgb_out, path_obj, path_sub);
+	if (P.n_grids) return launch_render<kModeList, true>(stream, P, objs, grids, list, n_waves, rgb_out, path_obj, path_sub);
+	return launch_render<kModeList, false>(stream, P, objs, grids, list, n_waves, rgb_out, path_obj, path_sub);
 }
 
 hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8, size_t n, double sample_count, double exposure,

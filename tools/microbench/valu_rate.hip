@@ -21,6 +21,15 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int n, uint32_t seed) {
 			if (OP == 6) d[i] = d[i] + 1e-7;                                  // v_add_f64
 			if (OP == 7) d[i] = __builtin_amdgcn_rcp(d[i]) + 1.0;             // v_rcp_f64 (+add)
 			if (OP == 8) d[i] = __builtin_amdgcn_rsq(d[i]) + 1.0;             // v_rsq_f64 (+add)
+			if (OP == 9) d[i] = __builtin_amdgcn_div_fixup(d[i], 1.5, 2.5);   // v_div_fixup_f64
+			if (OP == 10) d[i] = __builtin_amdgcn_div_fmas(d[i], 1.0000001, 1e-9, (a[i] & 1u) != 0u); // v_div_fmas_f64 (+ and/cmp)
+			if (OP == 11) { bool f; d[i] = __builtin_amdgcn_div_scale(d[i], 3.0, true, &f); } // v_div_scale_f64
+			if (OP == 12) d[i] = __builtin_ldexp(d[i], 1) * 0.5;             // v_ldexp_f64 + mul
+			if (OP == 13) d[i] = __builtin_rint(d[i] * 1.7);                  // v_rndne_f64 + mul
+			if (OP == 14) d[i] = (double)(int)d[i] + 1.5;                     // v_cvt_i32_f64 + v_cvt_f64_i32 + add
+			if (OP == 15) d[i] = (d[i] < 2.0) ? d[i] + 1.0 : 1.0;             // v_cmp_lt_f64 + add + 2 cndmask
+			if (OP == 16) d[i] = d[i] / 1.0000001;                            // full IEEE division
+			if (OP == 17) d[i] = __builtin_sqrt(d[i]) + 1.0;                  // full IEEE sqrt + add
 		}
 	}
 	uint32_t r = 0;
@@ -58,5 +67,14 @@ int main() {
 	run<6>("v_add_f64", 1);
 	run<7>("v_rcp_f64 + add", 2);
 	run<8>("v_rsq_f64 + add", 2);
+	run<9>("v_div_fixup_f64", 1);
+	run<10>("v_div_fmas_f64 + and + cmp", 3);
+	run<11>("v_div_scale_f64", 1);
+	run<12>("v_ldexp_f64 + mul", 2);
+	run<13>("v_rndne_f64 + mul", 2);
+	run<14>("cvt_i32_f64 + cvt_f64_i32 + add", 3);
+	run<15>("cmp_lt_f64 + add + 2 cndmask", 4);
+	run<16>("IEEE f64 division", 13);
+	run<17>("IEEE f64 sqrt + add", 20);
 	return 0;
 }
