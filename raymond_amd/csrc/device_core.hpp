@@ -237,6 +237,26 @@ RMD_DEV void onb(V3 n, V3 &t, V3 &b) {
 RMD_DEV V3 mat3_mul(V3 c0, V3 c1, V3 c2, V3 v) {
 	return mk((c0.x * v.x + c1.x * v.y) + c2.x * v.z, (c0.y * v.x + c1.y * v.y) + c2.y * v.z, (c0.z * v.x + c1.z * v.y) + c2.z * v.z);
 }
+// Fused multiply-adds whose constant operand is held in a scalar register pair.  Written as inline assembly because the
+// compiler otherwise materialises the twelve polynomial coefficients of sincos_cw in vector registers, hoists them out of
+// the render loop and — at the grid kernel's register limit — spills them, so that every Horner step waited on a scratch
+// load (22 dependent scratch round trips per shading pass).  A VALU instruction may read one scalar operand.
+RMD_DEV double fma_vvs(double a, double b, double c_uniform) { // a * b + C
+	double d;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+	return d;
+}
+RMD_DEV double fma_vs(double a, double b_uniform, double c) { // a * B + c
+	double d;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+	return d;
+}
+RMD_DEV double fma_ss(double a, double b_uniform, double c_uniform) { // a * B + C: C is copied to a vector register on the spot
+	double c;
+	asm volatile("v_mov_b64 %0, %1" : "=v"(c) : "s"(c_uniform)); // volatile: not to be hoisted out of the loop (and spilled) again
+	return fma_vs(a, b_uniform, c);
+}
+
 // sin and cos of one angle (the reference calls libm sin() and cos(), src/trace.rs:401-403 and :291-293).  The angles on
 // this path are 2*pi*u and the GGX angle roughness^2 * sqrt(u/(1-u)) with u < 1 - 2^-53, so the general-purpose sincos
 // (140 instructions, most of them for arguments this path never produces) is replaced by: quadrant count
@@ -248,20 +268,20 @@ RMD_DEV V3 mat3_mul(V3 c0, V3 c1, V3 c2, V3 v) {
 // exceed that (kMaxRoughness).  Inf and NaN give NaN, as in libm.
 RMD_DEV void sincos_cw(double x, double &s, double &c) {
 	const double k = __builtin_rint(x * 6.36619772367581382433e-01);
-	double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
-	r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+	double r = fma_vs(-k, 1.57079632679489655800e+00, x);
+	r = fma_vs(-k, 6.12323399573676603587e-17, r);
 	const double z = r * r;
-	double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-	ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-	ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-	ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-	ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+	double ps = fma_ss(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+	ps = fma_vvs(z, ps, 2.75573137070700676789e-06);
+	ps = fma_vvs(z, ps, -1.98412698298579493134e-04);
+	ps = fma_vvs(z, ps, 8.33333333332248946124e-03);
+	ps = fma_vvs(z, ps, -1.66666666666666324348e-01);
 	const double sr = __builtin_fma(r * z, ps, r);
-	double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-	pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-	pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-	pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-	pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+	double pc = fma_ss(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+	pc = fma_vvs(z, pc, -2.75573143513906633035e-07);
+	pc = fma_vvs(z, pc, 2.48015872894767294178e-05);
+	pc = fma_vvs(z, pc, -1.38888888888741095749e-03);
+	pc = fma_vvs(z, pc, 4.16666666666666019037e-02);
 	const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
 	const int n = (int)__builtin_fma(-4.0, __builtin_rint(k * 0.25), k); // k mod 4 in {-2..2}: k itself may not fit an int
 	const double ss = (n & 1) ? cr : sr, cc = (n & 1) ? sr : cr;
