@@ -164,6 +164,9 @@ RMD_DEV bool triangle_intersect(V3 v0, V3 edge1, V3 edge2, V3 ro, V3 rd, double 
 	constexpr double EPSILON = 0.00000001;
 	V3 h = cross(rd, edge2);
 	double a = dot(edge1, h);
+	// v0 is only needed behind the determinant test, and the compiler would sink its load there: a second dependent
+	// memory round trip per test.  Nearly every test passes the determinant, so pin the load in front of the branch.
+	asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v0.z));
 	if (a < EPSILON && a > -EPSILON) return false;
 	double f = 1.0 / a;
 	V3 s = ro - v0;
