@@ -308,6 +308,10 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		d.tri_pos = (const double *)p;
 		RMD_SCENE_HIP(upload(g.tri_nrm, g.n_tris * 9 * sizeof(double), &p));
 		d.tri_nrm = (const double *)p;
+		std::vector<double> aux((size_t)g.n_tris * 4);
+		for (uint64_t ti = 0; ti < g.n_tris; ti++) rmd::triangle_aux(g.tri_pos + (size_t)ti * 9, aux.data() + (size_t)ti * 4);
+		RMD_SCENE_HIP(upload(aux.data(), aux.size() * sizeof(double), &p));
+		d.tri_aux = (const double *)p;
 	}
 	void *p = nullptr;
 	RMD_SCENE_HIP(upload(hobj.data(), hobj.size() * sizeof(rmd::DevObject), &p));

@@ -183,21 +183,37 @@ RMD_DEV bool triangle_intersect(V3 v0, V3 edge1, V3 edge2, V3 ro, V3 rd, double 
 	return false;
 }
 // triangle.rs:47-68
-RMD_DEV double heron_area(V3 a, V3 b, V3 c) {
-	double ab = dist(a, b), ac = dist(a, c), bc = dist(b, c);
+RMD_DEV double heron_area_of_sides(double ab, double ac, double bc) {
 	double s = (ab + ac + bc) / 2.0;
 	return sqrt64(s * (s - ab) * (s - ac) * (s - bc));
 }
+RMD_DEV double heron_area(V3 a, V3 b, V3 c) { return heron_area_of_sides(dist(a, b), dist(a, c), dist(b, c)); }
+// The reference evaluates three Heron areas per shaded mesh hit — (p0,p1,p2), (p0,p1,P), (p0,p2,P) — i.e. six distances and
+// three more square roots.  |p0p1|, |p0p2| and the area of the triangle itself do not depend on the hit point: the scene
+// upload precomputes them with the same operations (internal.hpp: triangle_aux; IEEE + - * / sqrt on both sides, so the
+// values are the ones the kernel would compute), which leaves three distances and two areas here — about half the work of
+// a block that runs on nearly every trip of a mesh scene for the few lanes that hit the mesh.
+// aux = { |p0p1|, |p0p2|, area(p0,p1,p2), unused }.
 template <class P>
-RMD_DEV V3 triangle_normal(P pos9, P nrm9, V3 position) {
+RMD_DEV V3 triangle_normal_with(P pos9, P nrm9, double side_ab, double side_ac, double abc, V3 position) {
 	V3 p0 = ld3(pos9), p1 = ld3(pos9 + 3), p2 = ld3(pos9 + 6);
-	double abc = heron_area(p0, p1, p2);
-	double abp = heron_area(p0, p1, position);
-	double bcp = heron_area(p0, p2, position);
+	const double d0 = dist(p0, position), d1 = dist(p1, position), d2 = dist(p2, position);
+	double abp = heron_area_of_sides(side_ab, d0, d1); // heron_area(p0, p1, position)
+	double bcp = heron_area_of_sides(side_ac, d0, d2); // heron_area(p0, p2, position)
 	double ba = abp / abc, bb = bcp / abc;
 	double bc = 1.0 - (ba + bb);
 	V3 n = (ld3(nrm9 + 6) * ba) + (ld3(nrm9 + 3) * bb) + (ld3(nrm9) * bc);
 	return normalize(n);
+}
+template <class P>
+RMD_DEV V3 triangle_normal(P pos9, P nrm9, P aux4, V3 position) {
+	return triangle_normal_with(pos9, nrm9, aux4[0], aux4[1], aux4[2], position);
+}
+// the same with the triangle's own sides and area computed here (known-answer probe)
+template <class P>
+RMD_DEV V3 triangle_normal(P pos9, P nrm9, V3 position) {
+	V3 p0 = ld3(pos9), p1 = ld3(pos9 + 3), p2 = ld3(pos9 + 6);
+	return triangle_normal_with(pos9, nrm9, dist(p0, p1), dist(p0, p2), heron_area(p0, p1, p2), position);
 }
 
 // f64 -> i32 as num-traits NumCast does it (truncate; fail on NaN / out of range)

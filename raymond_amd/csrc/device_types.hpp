@@ -44,6 +44,7 @@ struct alignas(16) DevGrid {
 	const void *tri_runs;       // n_refs x 80 B
 	const double *tri_pos;      // n_tris * 9: v0 v1 v2 (Heron normal, triangle.rs:47-68)
 	const double *tri_nrm;      // n_tris * 9: n0 n1 n2
+	const double *tri_aux;      // n_tris * 4: |v0v1|, |v0v2|, Heron area of the triangle, pad (internal.hpp: triangle_aux)
 	const uint32_t *mask_words; // occupancy bitmask (global copy, staged into LDS by every workgroup)
 	uint64_t n_tris;
 	uint32_t mask_bits;         // number of valid bits; bit i covers cells [i << mask_shift, (i+1) << mask_shift)

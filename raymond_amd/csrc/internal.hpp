@@ -2,6 +2,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <cmath>
+
 #include <string>
 #include <vector>
 
@@ -54,6 +56,19 @@ struct rmd_grid_build {
 };
 
 namespace rmd {
+// Per-triangle constants of the Heron normal (triangle.rs:47-68): the two sides and the area that do not depend on the
+// hit point, with exactly the operations of device_core.hpp (dist = sqrt(((dx*dx + dy*dy) + dz*dz)), heron_area_of_sides):
+// every operation is a correctly rounded IEEE one and this file is compiled with -ffp-contract=off, so the values are
+// bit-identical to what the kernel would compute.  out = { |p0p1|, |p0p2|, area(p0,p1,p2), 0 }.
+inline void triangle_aux(const double *p9, double out[4]) {
+	auto dist = [](const double *a, const double *b) {
+		const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+		return std::sqrt((dx * dx + dy * dy) + dz * dz);
+	};
+	const double ab = dist(p9, p9 + 3), ac = dist(p9, p9 + 6), bc = dist(p9 + 3, p9 + 6);
+	const double s = (ab + ac + bc) / 2.0;
+	out[0] = ab, out[1] = ac, out[2] = std::sqrt(s * (s - ab) * (s - ac) * (s - bc)), out[3] = 0.0;
+}
 // Records `text` as the last error of `ctx` (or of the calling thread when ctx is null) and returns `status`.
 rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text);
 } // namespace rmd

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 					else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin)); // sphere.rs:31-35
 					else if constexpr (GRID) {
 						const DevGrid &g = grids[o.grid_index];
-						normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, frag); // acc_grid.rs:85-87
+						normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, as_global(g.tri_aux) + (size_t)sub * 4, frag); // acc_grid.rs:85-87
 					} else {
 						normal = mk(0.0, 0.0, 0.0); // unreachable: a scene with grid objects runs the GRID instantiation
 					}
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const dou
 	} break;
 	case PROBE_TRIANGLE_NORMAL: {
 		V3 frag = ld3(a + 18) + ld3(a + 21) * a[24];
-		V3 nn = triangle_normal(a, a + 9, frag);
+		V3 nn = triangle_normal(a, a + 9, a + 25, frag); // sides/area precomputed on the host, as for an uploaded scene
 		o[0] = nn.x, o[1] = nn.y, o[2] = nn.z;
 	} break;
 	case PROBE_ONB: {

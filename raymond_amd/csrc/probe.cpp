@@ -127,7 +127,9 @@ rmd_status rmd_probe_triangle_intersect(rmd_context *ctx, size_t n, const double
 rmd_status rmd_probe_triangle_normal(rmd_context *ctx, size_t n, const double *pos9, const double *nrm9, const double *ray6,
                                      const double *t, double *n3) {
 	std::vector<double> out;
-	if (rmd_status s = run_probe(ctx, rmd::PROBE_TRIANGLE_NORMAL, n, {{pos9, 9}, {nrm9, 9}, {ray6, 6}, {t, 1}}, 3, out)) return s;
+	std::vector<double> aux(n * 4);
+	for (size_t i = 0; i < n; i++) rmd::triangle_aux(pos9 + i * 9, aux.data() + i * 4); // as rmd_scene_create does
+	if (rmd_status s = run_probe(ctx, rmd::PROBE_TRIANGLE_NORMAL, n, {{pos9, 9}, {nrm9, 9}, {ray6, 6}, {t, 1}, {aux.data(), 4}}, 3, out)) return s;
 	unpack(out, 3, 0, 3, n3, n);
 	return RMD_OK;
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void wf_step(RenderParams P, WfState st, const
 				else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin));
 				else {
 					const DevGrid &g = grids[o.grid_index];
-					normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, frag);
+					normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, as_global(g.tri_aux) + (size_t)sub * 4, frag);
 				}
 				Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
 				const V3 wgt = bounce_weight(b);
