@@ -43,7 +43,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_OUT_OF_MEMORY, "rmd_context_create: allocation failed");
 	ctx->device = device;
 	ctx->n_cus = (uint32_t)prop.multiProcessorCount;
-	ctx->wave_slots = (uint32_t)prop.multiProcessorCount * 12u; // 3 waves/SIMD (grid-less kernel); the grid kernel holds 16 per CU
+	ctx->wave_slots = (uint32_t)prop.multiProcessorCount * 16u; // both render kernels fit 4 waves per SIMD (<= 128 VGPRs)
 	if (own_stream) {
 		hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 		if (se != hipSuccess) {
@@ -381,13 +381,12 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 		if (has_grid) {
 			// mesh tiles cost ~10x wall tiles, so their waves form a long tail even on a full 1080p frame (measured: 2-way
 			// split 115.7 -> 105.2 ms; the scratch traffic, 48 B/sample, is noise next to ~2.3 us of walk per sample)
-			const uint32_t slots = ctx->wave_slots / 12u * 16u; // the grid kernel holds 16 waves per CU
-			k = (8u * slots + n_wave_tiles - 1u) / n_wave_tiles;
+			k = (8u * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 			if (k < 2u) k = 2u;
-		} else if (n_wave_tiles < 4u * ctx->wave_slots) {
+		} else if (n_wave_tiles < 3u * ctx->wave_slots) {
 			// uniform tiles: split only when wave tiles are scarce (an N-way shard); on a full frame the 48 B/sample of
 			// scratch traffic costs 3 % and buys nothing
-			k = (8u * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
+			k = (6u * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		}
 	}
 	if (k > sample_count / 8u) k = sample_count / 8u; // keep >= 8 samples per wave: path regeneration needs a run of samples
