@@ -53,13 +53,22 @@ def _worker(rank, world, port, out_path):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_render_plus_reduce_equals_single_process(oracle, tmp_path, world):
-    import torch.multiprocessing as mp
+    import multiprocessing
 
     from raymond_amd import scenes, shard
     from raymond_amd.scene import Settings, generate_tiles
 
     out_path = str(tmp_path / "reduced.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    # the ranks are spawned with the standard library, so that this (parent) process never imports torch: a later GPU test
+    # in the same session would otherwise run libraymond_hip.so's RCCL path next to torch's bundled ROCm libraries
+    mp = multiprocessing.get_context("spawn")
+    port = _free_port()
+    procs = [mp.Process(target=_worker, args=(rank, world, port, out_path)) for rank in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     st = Settings(scenes.camera(160, 96), sample_count=3, tile_size=(32, 32), bounce_limit=4, seed=21)
     tiles = generate_tiles(160, 96, st.tile_size)
     full = oracle.OracleScene(scenes.reflective_spheres()).render_tiles(st.camera_settings, st, tiles, threads=2)
