@@ -226,7 +226,7 @@ def main():
         if bps is None:
             bps = 24.0 / spp
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
-        out["kernel"] = {"name": "rmd::render_kernel<false, %s>" % ("true" if scenes.CONFIGS[name][0] != "reflective_spheres" else "false"), "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]),
+        out["kernel"] = {"name": "rmd::render_kernel<%s>" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else "0, false"),  # <MODE, GRID> as rocprofv3 prints it "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]),
                          "checksum": main_run["checksum"]}
         out["roofline_%s" % name.lower()] = {
             "bound": "hbm", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -246,7 +246,7 @@ def main():
             "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": load_traffic("C3"),
             "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces" % rspp,
-            "kernel": "rmd::render_kernel<false, true>", "avg_ms": round(avg_ms, 3),
+            "kernel": "rmd::render_kernel<1, true>", "avg_ms": round(avg_ms, 3),
             "bytes_per_sample": round(bps, 2), "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
         }
     elif rank == 0:
