@@ -226,7 +226,7 @@ def main():
         if bps is None:
             bps = 24.0 / spp
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
-        out["kernel"] = {"name": "rmd::render_kernel<%s>" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else "0, false"),  # <MODE, GRID> as rocprofv3 prints it "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]),
+        out["kernel"] = {"name": "rmd::render_kernel<%s>" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else ("0, false" if world == 1 else "1, false")),  # <MODE, GRID> as rocprofv3 prints it; a shard is rendered with split samples (MODE 1) "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]),
                          "checksum": main_run["checksum"]}
         out["roofline_%s" % name.lower()] = {
             "bound": "hbm", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
