@@ -44,7 +44,8 @@ rmd_status rmd_probe_geometry_smith(rmd_context *ctx, size_t n, const double *n3
 rmd_status rmd_probe_fresnel_schlick(rmd_context *ctx, size_t n, const double *cos_theta, const double *f0_3, double *out3);
 /* The device's elementary functions as the kernels use them: IEEE sqrt (bit-exact) and the reduced-range sin / cos that
  * stand in for the reference's libm calls (src/trace.rs:291-293, :401-403; <= 2 ulp for |x| < 2^45). */
-rmd_status rmd_probe_elementary(rmd_context *ctx, size_t n, const double *x, double *sqrt_out, double *sin_out, double *cos_out);
+rmd_status rmd_probe_elementary(rmd_context *ctx, size_t n, const double *x, double *sqrt_out, double *sin_out, double *cos_out,
+                                double *root_out, double *inv_root_out); /* root/inv_root: normalize()'s sqrt and 1.0 / sqrt, both bit-exact */
 /* src/trace.rs:322-333 with the two jitter uniforms given explicitly (u2[2i], u2[2i+1]) */
 rmd_status rmd_probe_primary_ray(rmd_context *ctx, size_t n, const rmd_camera *cam, const uint32_t *xy2, const double *u2, double *ray6);
 /* core/src/scene.rs:54-74: obj[i] = object index or -1, sub[i] = triangle index for grid objects */

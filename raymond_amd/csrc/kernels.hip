@@ -366,6 +366,7 @@ __global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const dou
 	case PROBE_ELEMENTARY: { // the device's own sqrt / sin / cos (device_core.hpp)
 		o[0] = sqrt64(a[0]);
 		sincos_cw(a[0], o[1], o[2]);
+		sqrt_and_inverse(a[0], o[3], o[4]);
 	} break;
 	default: break;
 	}

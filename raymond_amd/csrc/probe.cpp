@@ -173,12 +173,15 @@ rmd_status rmd_probe_fresnel_schlick(rmd_context *ctx, size_t n, const double *c
 	unpack(out, 3, 0, 3, out3, n);
 	return RMD_OK;
 }
-rmd_status rmd_probe_elementary(rmd_context *ctx, size_t n, const double *x, double *sqrt_out, double *sin_out, double *cos_out) {
+rmd_status rmd_probe_elementary(rmd_context *ctx, size_t n, const double *x, double *sqrt_out, double *sin_out, double *cos_out,
+                                double *root_out, double *inv_root_out) {
 	std::vector<double> out;
-	if (rmd_status s = run_probe(ctx, rmd::PROBE_ELEMENTARY, n, {{x, 1}}, 3, out)) return s;
-	unpack(out, 3, 0, 1, sqrt_out, n);
-	unpack(out, 3, 1, 1, sin_out, n);
-	unpack(out, 3, 2, 1, cos_out, n);
+	if (rmd_status s = run_probe(ctx, rmd::PROBE_ELEMENTARY, n, {{x, 1}}, 5, out)) return s;
+	unpack(out, 5, 0, 1, sqrt_out, n);
+	unpack(out, 5, 1, 1, sin_out, n);
+	unpack(out, 5, 2, 1, cos_out, n);
+	unpack(out, 5, 3, 1, root_out, n);
+	unpack(out, 5, 4, 1, inv_root_out, n);
 	return RMD_OK;
 }
 rmd_status rmd_probe_primary_ray(rmd_context *ctx, size_t n, const rmd_camera *cam, const uint32_t *xy2, const double *u2, double *ray6) {

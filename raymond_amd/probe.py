@@ -25,7 +25,7 @@ _SIGS = {
     "rmd_probe_geometry_smith": [_vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "rmd_probe_fresnel_schlick": [_vp, _sz, _vp, _vp, _vp],
     "rmd_probe_primary_ray": [_vp, _sz, _P(abi.Camera), _vp, _vp, _vp],
-    "rmd_probe_elementary": [_vp, _sz, _vp, _vp, _vp, _vp],
+    "rmd_probe_elementary": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "rmd_probe_scene_intersect": [_vp, _vp, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_grid_intersect": [_vp, _vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_trace_samples": [_vp, _vp, _P(abi.Camera), _P(abi.Settings), _sz, _vp, _vp, _vp, _vp, _vp],
@@ -93,12 +93,12 @@ def uniform(ctx, seed, pixel, sample, draw):
 
 
 def elementary(ctx, x):
-    """-> (sqrt64(x), sin(x), cos(x)) as the device computes them"""
+    """-> (sqrt64(x), sin(x), cos(x), root, 1/root) as the device computes them (root, 1/root: normalize()'s pair)"""
     L = _L()
     x = _f(x).ravel()
-    s, si, co = np.zeros_like(x), np.zeros_like(x), np.zeros_like(x)
-    ctx.check(L.rmd_probe_elementary(ctx.handle, x.shape[0], _p(x), _p(s), _p(si), _p(co)))
-    return s, si, co
+    s, si, co, ro, ir = (np.zeros_like(x) for _ in range(5))
+    ctx.check(L.rmd_probe_elementary(ctx.handle, x.shape[0], _p(x), _p(s), _p(si), _p(co), _p(ro), _p(ir)))
+    return s, si, co, ro, ir
 
 
 def primary_ray(ctx, cam, xy, u):

@@ -200,12 +200,21 @@ def test_device_sqrt_is_exact_and_sincos_within_2ulp(gpu_ctx):
     mixed = np.ldexp(rng.uniform(0.5, 1.0, N), rng.integers(-1074, 1024, N))
     mixed[:16] = [0.0, -0.0, np.inf, -np.inf, np.nan, -1.0, 5e-324, 2.0**-1022, 2.0**-767, np.nextafter(2.0**-767, 0), 1.0, 4.0, 2.0, 1e-300, 1e300, -5e-324]
     x = np.concatenate([normal, mixed])
-    got, _, _ = probe.elementary(gpu_ctx, x)
+    got, _, _, root, inv = probe.elementary(gpu_ctx, x)
     with np.errstate(invalid="ignore"):
         want = np.sqrt(x)
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan)
     assert np.array_equal(got[~nan].view(np.uint64), want[~nan].view(np.uint64))  # bit for bit, signed zeros included
+    # normalize()'s pair: sqrt and the reciprocal of the rounded root, shortcut and guarded plain path alike
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want_inv = 1.0 / want
+    assert np.array_equal(root[~nan].view(np.uint64), want[~nan].view(np.uint64))
+    assert np.array_equal(inv[~nan].view(np.uint64), want_inv[~nan].view(np.uint64))
+    ones = (np.ldexp(2.0 - 2.0**-52, rng.integers(-300, 300, N)) * (1.0 - rng.integers(0, 3, N) * 2.0**-53)) ** 2  # roots next to all-ones
+    _, _, _, root, inv = probe.elementary(gpu_ctx, ones)
+    assert np.array_equal(root.view(np.uint64), np.sqrt(ones).view(np.uint64))
+    assert np.array_equal(inv.view(np.uint64), (1.0 / np.sqrt(ones)).view(np.uint64))
 
     u = rng.uniform(0, 1, N)
     args = np.concatenate([
@@ -215,7 +224,7 @@ def test_device_sqrt_is_exact_and_sincos_within_2ulp(gpu_ctx):
         np.arange(64) * (np.pi / 2),                                 # next to the quadrant boundaries
         [0.0, 1.0 - 2.0**-53, 9.49e7, 2.0**27, 2.0**40],
     ])
-    _, si, co = probe.elementary(gpu_ctx, args)
+    _, si, co, _, _ = probe.elementary(gpu_ctx, args)
     ref_s, ref_c = np.sin(args.astype(np.longdouble)), np.cos(args.astype(np.longdouble))
     for got, ref in ((si, ref_s), (co, ref_c)):
         err = np.abs(got.astype(np.longdouble) - ref).astype(np.float64)
