@@ -6,13 +6,15 @@
 // that loop leaves ~90 % of the lanes idle and chains 2-4 dependent memory latencies per cell.  Here:
 //
 //   1. every lane steps ITS OWN ray's DDA (bit-identical arithmetic, :100-125 and :155-183) but skips empty
-//      cells with an occupancy bitmask held in LDS — no global memory access until a candidate cell;
-//   2. lanes standing on candidate cells fetch their 8-byte cell entry {first record, count} together;
-//   3. for each such (lane, cell) pair in turn the WHOLE WAVE tests that cell's triangles, one triangle per
-//      lane: the ray is broadcast through SGPRs (v_readlane), the cell's triangle records are contiguous
-//      80-byte rows (coalesced), and the winner is picked by a scalar loop over the hit ballot in ascending
-//      lane order with a strict '<' — the reference's `if distance < closest` scan (:137-149) exactly,
-//      including the 5712515.0 start value and first-wins ties.
+//      cells with an occupancy bitmask held in LDS — no global memory access until a candidate cell — and
+//      collects up to kWalkCand candidate cells per round (it steps past a candidate speculatively);
+//   2. the lanes fetch the 8-byte entries {first record, count} of their candidates together;
+//   3. all triangle tests of the round — every (lane, candidate, triangle) — are numbered by a prefix sum and
+//      taken by the WHOLE WAVE 64 at a time, one test per lane: the test's ray comes from its owner lane's
+//      registers (ds_bpermute), the cell's triangle records are contiguous 80-byte rows (coalesced), and the
+//      winner is picked by a scalar loop over the hit ballot in ascending (lane, candidate, triangle) order with
+//      a strict '<' — the reference's `if distance < closest` scan (:137-149) exactly, including the 5712515.0
+//      start value and first-wins ties; the earliest candidate cell with an accepted hit wins (:151-153).
 // Results are therefore identical to the sequential walk for every ray.
 #pragma once
 #include "device_core.hpp"
