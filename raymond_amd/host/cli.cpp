@@ -5,6 +5,9 @@
 //   raymond_cli mesh N out.bin            procedural stand-in mesh as raw f64 (tri_pos then tri_nrm)
 //   raymond_cli ply in.ply out.bin        Mesh::load_ply + bake_transform(0,-0.3,2.9), raw f64 as above
 //   raymond_cli tiles W H TW TH           tile generation order of render_tiled, one "left top width height" per line
+//   raymond_cli project in.json dump|json Project::load (core/src/project.rs): flattened scene, or the re-serialised JSON
+//   raymond_cli tilemsg W H               a TileFinished message in the wire form of server/src/protocol.rs
+//   (render also accepts `project:in.json` as its scene)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +39,37 @@ int main(int argc, char **argv) {
 			std::printf("%zu triangles\n", m.triangle_count());
 			return 0;
 		}
+		if (argc >= 4 && !std::strcmp(argv[1], "project")) {
+			Project p = Project::load(argv[2]);
+			if (!std::strcmp(argv[3], "json")) {
+				std::printf("%s\n", p.dumps().c_str());
+				return 0;
+			}
+			Scene sc = p.build_scene();
+			for (const Object &o : sc.objects) {
+				const Geometry &g = o.geometry;
+				if (g.kind == RMD_GEOM_PLANE) std::printf("plane %.17g %.17g %.17g %.17g %.17g %.17g", g.plane.origin[0], g.plane.origin[1], g.plane.origin[2], g.plane.normal[0], g.plane.normal[1], g.plane.normal[2]);
+				else if (g.kind == RMD_GEOM_SPHERE) std::printf("sphere %.17g %.17g %.17g %.17g", g.sphere.origin[0], g.sphere.origin[1], g.sphere.origin[2], g.sphere.radius);
+				else {
+					const rmd_grid_desc &d = g.grid->desc();
+					unsigned long long h = 1469598103934665603ull; // FNV-1a over cells then mapping_table
+					for (uint64_t i = 0; i < d.n_cells; i++) h = (h ^ d.cells[i]) * 1099511628211ull;
+					for (uint64_t i = 0; i < d.n_mapping; i++) h = (h ^ d.mapping_table[i]) * 1099511628211ull;
+					std::printf("grid %u %u %u %llu %llu %llu", d.resolution[0], d.resolution[1], d.resolution[2], (unsigned long long)d.n_tris, (unsigned long long)d.n_mapping, h);
+				}
+				const Material &m = o.material;
+				std::printf(" | %u %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", m.kind, m.color[0], m.color[1], m.color[2], m.roughness, m.aux[0], m.aux[1], m.aux[2], m.aux[3], m.aux[4]);
+			}
+			return 0;
+		}
+		if (argc >= 4 && !std::strcmp(argv[1], "tilemsg")) {
+			Message msg;
+			msg.kind = Message::TileFinished;
+			msg.tile.width = std::atoi(argv[2]), msg.tile.height = std::atoi(argv[3]), msg.tile.left = 32, msg.tile.top = 64, msg.tile.sample_count = 7;
+			for (size_t i = 0; i < msg.tile.width * msg.tile.height; i++) msg.tile.data.push_back({0.125 * (double)i, 1.0 / (double)(i + 3), -2.5e-7 * (double)i});
+			std::printf("%s\n", message_to_json(msg).c_str());
+			return 0;
+		}
 		if (argc >= 6 && !std::strcmp(argv[1], "tiles")) {
 			for (const rmd_tile_rect &t : generate_tiles(std::atoi(argv[2]), std::atoi(argv[3]), {std::atoi(argv[4]), std::atoi(argv[5])}))
 				std::printf("%u %u %u %u\n", t.left, t.top, t.width, t.height);
@@ -60,6 +94,7 @@ int main(int argc, char **argv) {
 			Scene scene;
 			if (what == "spheres") scene = reflective_spheres();
 			else if (what.rfind("dragon", 0) == 0) scene = gold_dragon_standin(what.size() > 7 ? std::atoi(what.c_str() + 7) : 91);
+			else if (what.rfind("project:", 0) == 0) scene = Project::load(what.substr(8)).build_scene(); // core/src/project.rs
 			else throw Error(RMD_ERR_INVALID_ARGUMENT, "unknown scene " + what);
 			TaskHandle handle = render_tiled(scene, st); // :152
 			size_t progressed = 0;

@@ -162,6 +162,26 @@ std::vector<rmd_tile_rect> generate_tiles(size_t width, size_t height, std::pair
 std::vector<uint8_t> tone_map(const std::vector<Vector3> &image, double exposure = 1.0, double gamma = 2.2);
 void write_ppm(const std::string &path, const std::vector<uint8_t> &rgb8, size_t width, size_t height);
 
+// core/src/project.rs:13-57 — the scene file: serde-JSON, enums externally tagged ({"Plane":{..}} | {"Sphere":{..}} |
+// {"Mesh":"file.ply"}; {"Diffuse":[V,r]} | {"Metal":[V,r]} | {"Emission":[V,V,f,f]}), Vector3 as {"x","y","z"} or [x,y,z].
+struct ProjectObject {
+	enum Kind { PlaneGeometry, SphereGeometry, MeshGeometry } kind = PlaneGeometry;
+	Plane plane{};
+	Sphere sphere{};
+	std::string mesh_path; // Geometry::Mesh(PathBuf)
+	Material material{};
+};
+struct Project {
+	std::vector<ProjectObject> objects;
+	std::string base_dir; // directory of the project file: relative mesh paths are resolved against it (as raymond_amd/project.py does)
+	static Project load(const std::string &path);                                       // project.rs:33-36
+	static Project loads(const std::string &json_text, const std::string &base_dir = ""); // serde_json::from_str
+	std::string dumps() const;                                                           // serde_json::to_string
+	Scene build_scene() const; // project.rs:38-57: meshes through Mesh::load_ply + AccGrid::build_from_mesh
+};
+// server/src/protocol.rs:9-14: {"type":"TileProgressed"|"TileFinished","data":{sample_count,width,height,left,top,data:[V..]}}
+std::string message_to_json(const Message &message);
+
 // Benchmark inputs, identical to raymond_amd/scenes.py
 Scene reflective_spheres();
 Mesh lumpy_sphere_mesh(int n = 91, Vector3 extent = {2.3, 1.7, 1.0}, Vector3 centre = {0.0, 0.15, 0.0});

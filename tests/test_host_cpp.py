@@ -77,14 +77,19 @@ def test_render_without_a_gpu_fails_loudly(cli, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene,spi", [("spheres", 0), ("dragon:12", 0), ("spheres", 3)])
+@pytest.mark.parametrize("scene,spi", [("spheres", 0), ("dragon:12", 0), ("spheres", 3), ("project", 0)])
 def test_cpp_render_tiled_equals_python_path(cli, gpu_ctx, tmp_path, scene, spi):
     W, H, spp, bounces = 96, 64, 7, 4
     ppm, raw = tmp_path / "o.ppm", tmp_path / "o.f64"
+    if scene == "project":  # the spheres scene through its serde-JSON project file (core/src/project.rs)
+        from raymond_amd.project import Project
+
+        (tmp_path / "spheres.json").write_text(Project.from_scene(scenes.reflective_spheres()).dumps())
+        scene = "project:%s" % (tmp_path / "spheres.json")
     r = run(cli, "render", scene, W, H, spp, bounces, ppm, "--raw", raw, "--spi", spi)
     assert r.returncode == 0, r.stderr
     img_cpp = np.fromfile(raw).reshape(H, W, 3)
-    sc = scenes.reflective_spheres() if scene == "spheres" else scenes.gold_dragon_standin(n=12)
+    sc = scenes.gold_dragon_standin(n=12) if scene.startswith("dragon") else scenes.reflective_spheres()
     st = Settings(scenes.camera(W, H), sample_count=spp, tile_size=(32, 32), bounce_limit=bounces, seed=scenes.SEED)
     ds = render.DeviceScene(gpu_ctx, sc)
     fb = render.Framebuffer(gpu_ctx, W, H)
