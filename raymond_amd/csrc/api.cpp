@@ -131,6 +131,7 @@ RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rm
 	for (int a = 0; a < 3; a++) P.cam_pos[a] = cam->position[a];
 	P.width = (double)cam->backbuffer_width;
 	P.height = (double)cam->backbuffer_height;
+	P.inv_width = rmd::exact_reciprocal(P.width), P.inv_height = rmd::exact_reciprocal(P.height);
 	P.aspect = P.width / P.height;
 	P.tan_half_fov = std::tan(cam->fov_vert / 2.0 * PI / 180.0);
 	P.focal_length = cam->focal_length;

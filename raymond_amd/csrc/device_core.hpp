@@ -49,6 +49,15 @@ RMD_DEV double sqrt64(double x) {
 	return __builtin_amdgcn_class(x, 0x260) ? x : g; // +-0 and +inf return themselves (class mask: -0 | +0 | +inf)
 }
 RMD_DEV double length(V3 a) { return sqrt64(dot(a, a)); }
+// a / b for a divisor whose correctly rounded reciprocal r = 1.0 / b was computed beforehand (host: exact_reciprocal(),
+// internal.hpp): q = a*r, then Markstein's correction q + (a - b*q)*r with the residual exact in the FMA — three
+// instructions for the 13 + v_rcp_f64 of a division.  The result is the IEEE quotient for every divisor whose significand is
+// not all ones (the host stores NaN for those and for zero / extreme divisors, and the call sites then divide plainly);
+// tools/microbench/div_by_reciprocal_check.hip: 0 mismatches in 3.4e11 quotients.  a must be finite.
+RMD_DEV double div_by(double a, double b, double r) {
+	const double q = a * r;
+	return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
 // root = sqrt(x) and inv = 1.0 / root, both correctly rounded — the two operations of cgmath's normalize — for the price of
 // the square root plus five FMAs.  The root's refinement already carries h ~ 1/(2*root); one Newton step on 2h and the
 // IEEE division's own final correction (e = 1 - root*r; inv = r + e*r) give the quotient the 13-instruction division
@@ -228,25 +237,27 @@ RMD_DEV double heron_area(V3 a, V3 b, V3 c) { return heron_area_of_sides(dist(a,
 // a block that runs on nearly every trip of a mesh scene for the few lanes that hit the mesh.
 // aux = { |p0p1|, |p0p2|, area(p0,p1,p2), unused }.
 template <class P>
-RMD_DEV V3 triangle_normal_with(P pos9, P nrm9, double side_ab, double side_ac, double abc, V3 position) {
+RMD_DEV V3 triangle_normal_with(P pos9, P nrm9, double side_ab, double side_ac, double abc, double inv_abc, V3 position) {
 	V3 p0 = ld3(pos9), p1 = ld3(pos9 + 3), p2 = ld3(pos9 + 6);
 	const double d0 = dist(p0, position), d1 = dist(p1, position), d2 = dist(p2, position);
 	double abp = heron_area_of_sides(side_ab, d0, d1); // heron_area(p0, p1, position)
 	double bcp = heron_area_of_sides(side_ac, d0, d2); // heron_area(p0, p2, position)
-	double ba = abp / abc, bb = bcp / abc;
+	double ba, bb;
+	if (inv_abc == inv_abc && abp < kFMax && bcp < kFMax) ba = div_by(abp, abc, inv_abc), bb = div_by(bcp, abc, inv_abc);
+	else ba = abp / abc, bb = bcp / abc; // degenerate or all-ones area, or a non-finite numerator: the plain divisions
 	double bc = 1.0 - (ba + bb);
 	V3 n = (ld3(nrm9 + 6) * ba) + (ld3(nrm9 + 3) * bb) + (ld3(nrm9) * bc);
 	return normalize(n);
 }
 template <class P>
 RMD_DEV V3 triangle_normal(P pos9, P nrm9, P aux4, V3 position) {
-	return triangle_normal_with(pos9, nrm9, aux4[0], aux4[1], aux4[2], position);
+	return triangle_normal_with(pos9, nrm9, aux4[0], aux4[1], aux4[2], aux4[3], position);
 }
 // the same with the triangle's own sides and area computed here (known-answer probe)
 template <class P>
 RMD_DEV V3 triangle_normal(P pos9, P nrm9, V3 position) {
 	V3 p0 = ld3(pos9), p1 = ld3(pos9 + 3), p2 = ld3(pos9 + 6);
-	return triangle_normal_with(pos9, nrm9, dist(p0, p1), dist(p0, p2), heron_area(p0, p1, p2), position);
+	return triangle_normal_with(pos9, nrm9, dist(p0, p1), dist(p0, p2), heron_area(p0, p1, p2), __builtin_nan(""), position);
 }
 
 // f64 -> i32 as num-traits NumCast does it (truncate; fail on NaN / out of range)
@@ -473,8 +484,11 @@ RMD_DEV V3 bounce_weight(const Bounce &b) {
 RMD_DEV void primary_ray(const RenderParams &P, uint32_t xi, uint32_t yi, double u0, double u1, V3 &ro, V3 &rd) {
 	double x = (double)xi + (u0 - 0.5);
 	double y = (double)yi + (u1 - 0.5);
-	double px = (2.0 * ((x + 0.5) / P.width) - 1.0) * P.tan_half_fov * P.aspect;
-	double py = (1.0 - 2.0 * ((y + 0.5) / P.height)) * P.tan_half_fov;
+	// (x + 0.5) / width and (y + 0.5) / height (:326-327) through the exact reciprocals when the host provided them
+	const double sx = P.inv_width == P.inv_width ? div_by(x + 0.5, P.width, P.inv_width) : (x + 0.5) / P.width;
+	const double sy = P.inv_height == P.inv_height ? div_by(y + 0.5, P.height, P.inv_height) : (y + 0.5) / P.height;
+	double px = (2.0 * sx - 1.0) * P.tan_half_fov * P.aspect;
+	double py = (1.0 - 2.0 * sy) * P.tan_half_fov;
 	ro = ld3(P.cam_pos);
 	rd = normalize(mk(px, py, 1.0));
 }

@@ -44,7 +44,7 @@ struct alignas(16) DevGrid {
 	const void *tri_runs;       // n_refs x 80 B
 	const double *tri_pos;      // n_tris * 9: v0 v1 v2 (Heron normal, triangle.rs:47-68)
 	const double *tri_nrm;      // n_tris * 9: n0 n1 n2
-	const double *tri_aux;      // n_tris * 4: |v0v1|, |v0v2|, Heron area of the triangle, pad (internal.hpp: triangle_aux)
+	const double *tri_aux;      // n_tris * 4: |v0v1|, |v0v2|, Heron area of the triangle, its exact reciprocal or NaN (internal.hpp: triangle_aux)
 	const uint32_t *mask_words; // occupancy bitmask (global copy, staged into LDS by every workgroup)
 	uint64_t n_tris;
 	uint32_t mask_bits;         // number of valid bits; bit i covers cells [i << mask_shift, (i+1) << mask_shift)
@@ -65,6 +65,7 @@ static_assert(sizeof(WaveTile) == 8, "WaveTile layout");
 struct RenderParams {
 	double cam_pos[3];
 	double width, height;  // backbuffer size as f64 (:323-324)
+	double inv_width, inv_height; // 1.0 / width, 1.0 / height, correctly rounded (host): divisors of div_by() in primary_ray
 	double aspect;         // width / height (:325)
 	double tan_half_fov;   // tan(fov_vert / 2 * PI / 180) (:329-330)
 	double focal_length;

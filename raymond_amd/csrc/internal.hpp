@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstring>
 
 #include <string>
 #include <vector>
@@ -59,7 +60,17 @@ namespace rmd {
 // Per-triangle constants of the Heron normal (triangle.rs:47-68): the two sides and the area that do not depend on the
 // hit point, with exactly the operations of device_core.hpp (dist = sqrt(((dx*dx + dy*dy) + dz*dz)), heron_area_of_sides):
 // every operation is a correctly rounded IEEE one and this file is compiled with -ffp-contract=off, so the values are
-// bit-identical to what the kernel would compute.  out = { |p0p1|, |p0p2|, area(p0,p1,p2), 0 }.
+// bit-identical to what the kernel would compute.  out = { |p0p1|, |p0p2|, area(p0,p1,p2), exact_reciprocal(area) }.
+// r = 1.0 / b for use by the device's div_by(a, b, r) (device_core.hpp), or NaN when that shortcut is not exact for this
+// divisor: Markstein's correction needs the correctly rounded reciprocal (this division) and fails for a divisor whose
+// significand is all ones; zero, non-finite and extreme divisors are left to the IEEE division as well.
+inline double exact_reciprocal(double b) {
+	uint64_t bits;
+	std::memcpy(&bits, &b, 8);
+	const double m = std::fabs(b);
+	if (!(m >= 0x1p-500 && m <= 0x1p500) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull) return std::nan("");
+	return 1.0 / b;
+}
 inline void triangle_aux(const double *p9, double out[4]) {
 	auto dist = [](const double *a, const double *b) {
 		const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
@@ -67,7 +78,7 @@ inline void triangle_aux(const double *p9, double out[4]) {
 	};
 	const double ab = dist(p9, p9 + 3), ac = dist(p9, p9 + 6), bc = dist(p9 + 3, p9 + 6);
 	const double s = (ab + ac + bc) / 2.0;
-	out[0] = ab, out[1] = ac, out[2] = std::sqrt(s * (s - ab) * (s - ac) * (s - bc)), out[3] = 0.0;
+	out[0] = ab, out[1] = ac, out[2] = std::sqrt(s * (s - ab) * (s - ac) * (s - bc)), out[3] = exact_reciprocal(out[2]);
 }
 // Records `text` as the last error of `ctx` (or of the calling thread when ctx is null) and returns `status`.
 rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text);
