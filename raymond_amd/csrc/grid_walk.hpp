@@ -110,6 +110,9 @@ constexpr uint32_t kWalkCand = RMD_WALK_CANDIDATES;
 static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 // After its first candidate a lane keeps stepping at most this many cells looking for more (the non-empty cells of
 // one surface crossing are adjacent); further cells wait for the next round.
+#ifndef RMD_WALK_ASM_STEP
+#define RMD_WALK_ASM_STEP 1
+#endif
 #ifndef RMD_WALK_LOOKAHEAD
 #define RMD_WALK_LOOKAHEAD 6
 #endif
@@ -225,6 +228,38 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			const uint32_t word = lds_mask[bit >> 5];
 			const uint32_t here = idx;
 			// the step (see above), computed while the mask word is in flight
+#if RMD_WALK_ASM_STEP
+			// The same step as the C++ below, written out: three compares, the three axis masks on the scalar unit, and each
+			// axis' {t_max += t_delta; counter -= 1; index += stride} under its mask — 12 vector instructions, no branches
+			// (the compiler's version re-evaluates a compare, routes the stride through a select and branches around two blocks).
+			{
+				unsigned long long m_xy, m_xz, saved;
+				asm("v_cmp_lt_f64 %[mxy], %[tmx], %[tmy]\n\t"
+				    "v_cmp_lt_f64 %[mxz], %[tmx], %[tmz]\n\t"
+				    "v_cmp_lt_f64 vcc, %[tmy], %[tmz]\n\t"
+				    "s_mov_b64 %[sv], exec\n\t"
+				    "s_and_b64 %[mxz], %[mxy], %[mxz]\n\t"  // x:  tmx < tmy && tmx < tmz
+				    "s_andn2_b64 vcc, vcc, %[mxy]\n\t"      // y: !(tmx < tmy) && tmy < tmz   (masks only hold active lanes)
+				    "s_mov_b64 exec, %[mxz]\n\t"
+				    "v_add_f64 %[tmx], %[tmx], %[tdx]\n\t"
+				    "v_add_u32 %[rx], -1, %[rx]\n\t"
+				    "v_add_u32 %[idx], %[idx], %[dix]\n\t"
+				    "s_mov_b64 exec, vcc\n\t"
+				    "v_add_f64 %[tmy], %[tmy], %[tdy]\n\t"
+				    "v_add_u32 %[ry], -1, %[ry]\n\t"
+				    "v_add_u32 %[idx], %[idx], %[diy]\n\t"
+				    "s_or_b64 vcc, vcc, %[mxz]\n\t"
+				    "s_andn2_b64 exec, %[sv], vcc\n\t"      // z: the rest
+				    "v_add_f64 %[tmz], %[tmz], %[tdz]\n\t"
+				    "v_add_u32 %[rz], -1, %[rz]\n\t"
+				    "v_add_u32 %[idx], %[idx], %[diz]\n\t"
+				    "s_mov_b64 exec, %[sv]"
+				    : [tmx] "+v"(tmx), [tmy] "+v"(tmy), [tmz] "+v"(tmz), [rx] "+v"(remx), [ry] "+v"(remy), [rz] "+v"(remz), [idx] "+v"(idx),
+				      [mxy] "=&s"(m_xy), [mxz] "=&s"(m_xz), [sv] "=&s"(saved)
+				    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [dix] "v"(dix), [diy] "v"(diy), [diz] "v"(diz)
+				    : "vcc");
+			}
+#else
 			const bool lt_xy = tmx < tmy, lt_xz = tmx < tmz, lt_yz = tmy < tmz;
 			if (lt_xy && lt_xz) {
 				tmx += tdx, remx--, idx += (uint32_t)dix;
@@ -233,6 +268,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			} else {
 				tmz += tdz, remz--, idx += (uint32_t)diz;
 			}
+#endif
 			const uint32_t rem_min = remx < remy ? (remx < remz ? remx : remz) : (remy < remz ? remy : remz);
 			// left the grid (a range test fired), or the next cell is past the cell array (:129-131): the walk returns None
 			walking = rem_min != 0u && idx < idx_limit;
