@@ -113,10 +113,19 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	__syncthreads(); // the only workgroup barrier: from here on every wave runs on its own
 	const uint32_t *lds_masks = P.mask_words_total ? lmasks : nullptr;
 
-	uint32_t x, y, s, s_end;
-	bool alive;
-	size_t out_index;
+	constexpr bool to_buffer = MODE == kModeTilesBuffered;
+	// Per-lane work.  LIST: one (x, y, sample) entry.  Tiles, direct mode: lane = pixel, samples s .. s_end-1 one after the
+	// other, the lane keeps the sum.  Tiles, buffered mode: the wave owns a sample range of its tile and its (pixel, sample)
+	// pairs form a pool — item k is pixel slot k % 64 of sample k / 64 — from which a lane whose path has ended takes the
+	// next item, so no lane sits out while the longest pixel of the tile finishes (which lane computes a sample has no
+	// influence on its value: the RNG is keyed by pixel and sample, and sum_kernel adds the samples in order).
+	uint32_t x = 0, y = 0, s = 0, s_end = 0;
+	bool alive = false;
+	size_t out_index = 0;
 	uint32_t list_idx = 0;
+	WaveTile tile = {};
+	uint32_t wt = 0, pool_first = 0, pool_items = 0, next_item = 0; // wave-uniform (buffered mode)
+	uint32_t item = 0;                                               // this lane's pool item (buffered mode)
 	if (LIST) {
 		list_idx = (blockIdx.x * waves_per_wg + wave) * 64u + lane;
 		alive = list_idx < P.n_work;
@@ -127,30 +136,34 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		// work item = (wave tile, sample sub-range): with split_k > 1 the samples of a tile are spread over split_k
 		// waves (neighbouring waves, same tile) that store every sample's radiance to the sample buffer; sum_kernel then
 		// adds them to the pixel in sample order, so the result is the same sequential sum as with one wave per tile
-		const uint32_t item = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
-		const uint32_t split = MODE == kModeTilesBuffered ? P.split_k : 1u;
-		const uint32_t wt = item / split, part = item % split;
-		bool have = wt < P.n_work;
-		WaveTile t = reinterpret_cast<const WaveTile *>(work)[have ? wt : 0];
-		uint32_t lx = lane & 7u, ly = lane >> 3;
+		const uint32_t work_item = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
+		const uint32_t split = to_buffer ? P.split_k : 1u;
+		wt = work_item / split;
+		const uint32_t part = work_item % split;
+		const bool have = wt < P.n_work;
+		tile = reinterpret_cast<const WaveTile *>(work)[have ? wt : 0];
 		const uint32_t per_part = (P.sample_count + split - 1u) / split;
 		const uint32_t s_lo = part * per_part < P.sample_count ? part * per_part : P.sample_count;
 		const uint32_t s_hi = s_lo + per_part < P.sample_count ? s_lo + per_part : P.sample_count;
-		alive = have && lx < t.w && ly < t.h && s_hi > s_lo;
-		x = t.x0 + lx, y = t.y0 + ly;
-		s = P.sample_begin + s_lo, s_end = P.sample_begin + s_hi;
-		out_index = MODE == kModeTilesBuffered ? ((size_t)wt * P.sample_count * 64u + lane) * 3 : ((size_t)x + (size_t)y * P.W) * 3;
+		if constexpr (to_buffer) {
+			pool_first = s_lo;
+			pool_items = have ? (s_hi - s_lo) * 64u : 0u;
+		} else {
+			const uint32_t lx = lane & 7u, ly = lane >> 3;
+			alive = have && lx < tile.w && ly < tile.h && s_hi > s_lo;
+			x = tile.x0 + lx, y = tile.y0 + ly;
+			s = P.sample_begin + s_lo, s_end = P.sample_begin + s_hi;
+			out_index = ((size_t)x + (size_t)y * P.W) * 3;
+		}
 	}
-	const uint32_t pixel = y * P.W + x;
 	const bool writes = alive;
 
 	V3 acc = mk(0.0, 0.0, 0.0);
-	constexpr bool to_buffer = MODE == kModeTilesBuffered;
 	if (!LIST && alive && !to_buffer) acc = ld3(out + out_index);
 
 	const V3 cam_pos = ld3(P.cam_pos);
 	Rng rng;
-	rng.init(P.key0, P.key1, pixel, s);
+	rng.init(P.key0, P.key1, 0u, 0u);
 	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
 	uint32_t depth = 1; // depth argument of the trace() call being evaluated
 	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
@@ -159,12 +172,32 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 
 	// Wave-uniform main loop: all 64 lanes stay in it until every lane has finished its samples, so that finished
 	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated on `alive`.
-	while (__ballot(alive) != 0ull) {
+	for (;;) {
+		if constexpr (to_buffer) {
+			// hand the next pool items to the lanes that have none
+			const unsigned long long idle = __ballot(!alive);
+			if (idle != 0ull && next_item < pool_items) {
+				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+				next_item += (uint32_t)__popcll(idle);
+				if (!alive && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) // slots outside a ragged tile are skipped
+					item = k, alive = true, fresh = true;
+			}
+			if (__ballot(alive) == 0ull) {
+				if (next_item >= pool_items) break;
+				continue;
+			}
+		} else if (__ballot(alive) == 0ull) {
+			break;
+		}
 		bool terminal = false;
 		V3 L = mk(0.0, 0.0, 0.0);
 		if (alive && fresh) {
 			// src/trace.rs:199 — primary ray of sample s
-			rng.init(P.key0, P.key1, pixel, s);
+			if constexpr (to_buffer) {
+				x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
+				s = P.sample_begin + pool_first + (item >> 6);
+			}
+			rng.init(P.key0, P.key1, y * P.W + x, s);
 			bool ok = true;
 			if (P.use_dof) {
 				ok = primary_ray_dof(P, x, y, rng, ro, rd);
@@ -229,15 +262,16 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		}
 		if (alive && terminal) {
 			L = hadamard(T, L);
-			if (to_buffer) {
-				double *dst = P.sample_buf + out_index + (size_t)(s - P.sample_begin) * (64u * 3u);
+			if constexpr (to_buffer) {
+				double *dst = P.sample_buf + (((size_t)wt * P.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * 3u;
 				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+				alive = false; // the lane takes its next item at the top of the loop
 			} else {
 				acc = acc + L; // src/trace.rs:203
+				s++;
+				fresh = true;
+				if (s == s_end) alive = false;
 			}
-			s++;
-			fresh = true;
-			if (s == s_end) alive = false;
 		}
 	}
 
