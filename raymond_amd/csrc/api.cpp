@@ -390,7 +390,7 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 			k = (6u * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		}
 	}
-	if (k > sample_count / 8u) k = sample_count / 8u; // keep >= 8 samples per wave: path regeneration needs a run of samples
+	if (k > sample_count / 4u) k = sample_count / 4u; // keep >= 4 samples (256 pool items) per wave
 	if (k > 64u) k = 64u;
 	while (k > 1u && (uint64_t)n_wave_tiles * k > 0x7FFFFFFFull) k--; // work items are indexed in 32 bits
 	return k < 2u ? 1u : k;
