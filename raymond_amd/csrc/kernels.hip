@@ -71,6 +71,55 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	return best;
 }
 
+// The same scan in two parts, for the render loop of a scene with grids.  Scene::intersect keeps the first object on
+// distance ties, i.e. it returns the lexicographic minimum of (distance, object index) — so the objects may be visited
+// in any order as long as candidates are merged with that rule.  intersect_simple() visits planes and spheres and
+// reports whether the ray enters any grid's bounding box (acc_grid.rs:90); intersect_grids() later runs the cooperative
+// walks of the grid objects for the lanes that do, and merges.  Splitting the scan lets a lane WAIT for its walk until
+// enough other lanes of the wave need one too (kWalkBatch): a walk phase costs about the same for 15 rays as for 45,
+// because the wave steps until its longest walk ends either way.
+RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return t < t_best || (t == t_best && obj < obj_best); }
+RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, bool want, V3 ro, V3 rd,
+                              double &closest, int &best) {
+	closest = kFMax, best = -1;
+	bool enters = false;
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const DevObject &o = objs[i];
+		double t = 0.0;
+		bool hit = false;
+		if (o.geometry_kind == 0u) {
+			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
+		} else if (o.geometry_kind == 1u) {
+			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
+		} else {
+			const DevGrid &g = grids[o.grid_index];
+			double t_outer;
+			if (want && aabb_intersect(ld3(g.bbox_min), ld3(g.bbox_max), ro, rd, t_outer)) enters = true;
+		}
+		if (want && hit && t < closest) closest = t, best = (int)i; // index order + strict '<' = the lexicographic minimum so far
+	}
+	return enters;
+}
+RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, const uint32_t *lds_masks,
+                             WalkScratch &scr, bool walkers, V3 ro, V3 rd, double &closest, int &best, uint32_t &sub, uint32_t debug_flags,
+                             unsigned long long *dbg) {
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const DevObject &o = objs[i];
+		if (o.geometry_kind != 2u) continue; // uniform
+		const DevGrid &g = grids[o.grid_index];
+		bool hit = false;
+		double t = 0.0;
+		uint32_t tri = 0;
+		grid_intersect_wave(g, lds_masks + g.mask_lds_word, scr, walkers, ro, rd, hit, t, tri, debug_flags, dbg);
+		if (walkers && hit && lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = tri;
+	}
+}
+// Lanes of a wave that must be waiting for a grid walk before one is run (unless nothing else can make progress).
+#ifndef RMD_WALK_BATCH
+#define RMD_WALK_BATCH 32
+#endif
+constexpr uint32_t kWalkBatch = RMD_WALK_BATCH;
+
 // Occupancy targets (waves per SIMD), measured on MI355X: the grid walk is latency-bound and gains 1.6x from 4 waves/SIMD
 // (128 VGPRs, a few dozen spills) over 2; the grid-less kernel is VALU-bound and is fastest at 3 (168 VGPRs).
 #ifndef RMD_GRID_MINW
@@ -169,6 +218,11 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
 	uint32_t path_len = 0;
 	bool fresh = true;
+	// grid scenes: a ray's closest plane/sphere hit while the lane waits for the walk that settles the grids (see intersect_simple)
+	bool new_ray = false, waiting = false;
+	double part_t = kFMax;
+	int part_obj = -1;
+	uint32_t part_sub = 0;
 
 	// Wave-uniform main loop: all 64 lanes stay in it until every lane has finished its samples, so that finished
 	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated on `alive`.
@@ -207,7 +261,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			}
 			depth = 1;
 			T = mk(1.0, 1.0, 1.0);
-			fresh = false;
+			fresh = false, new_ray = true;
 			if (!ok) terminal = true;                  // reference panics here; the sample contributes zero
 			if (P.bounce_limit == 0u) terminal = true; // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237)
 		}
@@ -222,8 +276,26 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		// src/trace.rs:239
 		double t;
 		uint32_t sub;
-		const int oi = scene_intersect_wave<GRID>(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
-		if (want) {
+		int oi;
+		bool complete; // lanes whose closest hit is known on this trip
+		if constexpr (GRID) {
+			if (want && new_ray) {
+				waiting = intersect_simple(objs, P.n_objects, grids, true, ro, rd, part_t, part_obj);
+				part_sub = 0u, new_ray = false;
+			}
+			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
+			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= kWalkBatch || rm == 0ull)) {
+				intersect_grids(objs, P.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, P.debug_flags, P.debug_counters);
+				waiting = false;
+			}
+			complete = want && !waiting;
+			t = part_t, oi = part_obj, sub = part_sub;
+		} else {
+			oi = scene_intersect_wave<false>(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
+			complete = want;
+		}
+		if (complete) {
 			if (LIST && path_obj) {
 				size_t pi = (size_t)list_idx * (RMD_PATH_STRIDE) + path_len;
 				path_obj[pi] = oi;
@@ -255,6 +327,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 					const V3 wgt = bounce_weight(b); // same factors as :281-282 / :315-318, multiplied forward
 					T = hadamard(T, wgt);
 					ro = b.next_origin, rd = b.next_dir;
+					new_ray = true;
 					depth++;
 					if (depth > P.bounce_limit) terminal = true; // :235-237: the recursive call returns 0 at once
 				}
