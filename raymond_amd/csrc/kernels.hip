@@ -119,6 +119,11 @@ RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_obje
 #define RMD_WALK_BATCH 32
 #endif
 constexpr uint32_t kWalkBatch = RMD_WALK_BATCH;
+// ... or fewer than this many lanes could do anything else on this trip (a trip costs the same for 5 lanes as for 50)
+#ifndef RMD_WALK_MIN_RUNNABLE
+#define RMD_WALK_MIN_RUNNABLE 16
+#endif
+constexpr uint32_t kWalkMinRunnable = RMD_WALK_MIN_RUNNABLE;
 
 // Occupancy targets (waves per SIMD), measured on MI355X: the grid walk is latency-bound and gains 1.6x from 4 waves/SIMD
 // (128 VGPRs, a few dozen spills) over 2; the grid-less kernel is VALU-bound and is fastest at 3 (168 VGPRs).
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			}
 			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
 			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
-			if (wm != 0ull && ((uint32_t)__popcll(wm) >= kWalkBatch || rm == 0ull)) {
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= kWalkBatch || (uint32_t)__popcll(rm) < kWalkMinRunnable)) {
 				intersect_grids(objs, P.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, P.debug_flags, P.debug_counters);
 				waiting = false;
 			}
