@@ -124,6 +124,11 @@ constexpr uint32_t kWalkBatch = RMD_WALK_BATCH;
 #define RMD_WALK_MIN_RUNNABLE 16
 #endif
 constexpr uint32_t kWalkMinRunnable = RMD_WALK_MIN_RUNNABLE;
+// ... or this many trips have passed since the wave's last walk (scenes where few rays reach a grid: bounds the wait)
+#ifndef RMD_WALK_MAX_WAIT
+#define RMD_WALK_MAX_WAIT 4
+#endif
+constexpr uint32_t kWalkMaxWait = RMD_WALK_MAX_WAIT;
 
 // Occupancy targets (waves per SIMD), measured on MI355X: the grid walk is latency-bound and gains 1.6x from 4 waves/SIMD
 // (128 VGPRs, a few dozen spills) over 2; the grid-less kernel is VALU-bound and is fastest at 3 (168 VGPRs).
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	bool fresh = true;
 	// grid scenes: a ray's closest plane/sphere hit while the lane waits for the walk that settles the grids (see intersect_simple)
 	bool new_ray = false, waiting = false;
+	uint32_t trips_since_walk = 0; // wave-uniform
 	double part_t = kFMax;
 	int part_obj = -1;
 	uint32_t part_sub = 0;
@@ -290,7 +296,9 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			}
 			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
 			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
-			if (wm != 0ull && ((uint32_t)__popcll(wm) >= kWalkBatch || (uint32_t)__popcll(rm) < kWalkMinRunnable)) {
+			trips_since_walk++;
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= kWalkBatch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
+				trips_since_walk = 0;
 				intersect_grids(objs, P.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, P.debug_flags, P.debug_counters);
 				waiting = false;
 			}
