@@ -144,6 +144,8 @@ RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rm
 	P.mask_words_total = scene ? scene->mask_words_total : 0;
 	P.key0 = (uint32_t)st->seed, P.key1 = (uint32_t)(st->seed >> 32);
 	P.use_dof = cam->aperture_radius > 0.0 ? 1u : 0u;
+	P.walk_batch = rmd::kWalkBatchDefault;
+	if (const char *wb = std::getenv("RMD_WALK_BATCH")) P.walk_batch = (uint32_t)std::atoi(wb); // test hook: any value gives the same image
 	if (const char *dbg = std::getenv("RMD_DEBUG")) P.debug_flags = (uint32_t)std::atoi(dbg); // timing-only ablations; results are wrong
 	return P;
 }

@@ -79,6 +79,7 @@ struct RenderParams {
 	uint32_t n_work;     // wave tiles (tile mode) or list entries (list mode)
 	uint32_t use_dof;
 	uint32_t n_grids;
+	uint32_t walk_batch;       // lanes of a wave that must wait for a grid walk before one is run (launch.hpp: kWalkBatchDefault; RMD_WALK_BATCH overrides)
 	uint32_t mask_words_total; // LDS words reserved for the grids' occupancy masks
 	uint32_t split_k;          // >1: each wave tile's sample range is split over split_k waves writing to sample_buf
 	double *sample_buf;        // [wave tile][sample - sample_begin][lane][3] f64, only when split_k > 1

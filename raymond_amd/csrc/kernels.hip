@@ -76,7 +76,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 // in any order as long as candidates are merged with that rule.  intersect_simple() visits planes and spheres and
 // reports whether the ray enters any grid's bounding box (acc_grid.rs:90); intersect_grids() later runs the cooperative
 // walks of the grid objects for the lanes that do, and merges.  Splitting the scan lets a lane WAIT for its walk until
-// enough other lanes of the wave need one too (kWalkBatch): a walk phase costs about the same for 15 rays as for 45,
+// enough other lanes of the wave need one too (RenderParams::walk_batch): a walk phase costs about the same for 15 rays as for 45,
 // because the wave steps until its longest walk ends either way.
 RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return t < t_best || (t == t_best && obj < obj_best); }
 RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, bool want, V3 ro, V3 rd,
@@ -114,11 +114,8 @@ RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_obje
 		if (walkers && hit && lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = tri;
 	}
 }
-// Lanes of a wave that must be waiting for a grid walk before one is run (unless nothing else can make progress).
-#ifndef RMD_WALK_BATCH
-#define RMD_WALK_BATCH 32
-#endif
-constexpr uint32_t kWalkBatch = RMD_WALK_BATCH;
+// A walk is run when RenderParams::walk_batch lanes of the wave wait for one (launch.hpp: kWalkBatchDefault = 32, measured best
+// of 12..56 on the benchmark mesh),
 // ... or fewer than this many lanes could do anything else on this trip (a trip costs the same for 5 lanes as for 50)
 #ifndef RMD_WALK_MIN_RUNNABLE
 #define RMD_WALK_MIN_RUNNABLE 16
@@ -297,7 +294,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
 			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
 			trips_since_walk++;
-			if (wm != 0ull && ((uint32_t)__popcll(wm) >= kWalkBatch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= P.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
 				trips_since_walk = 0;
 				intersect_grids(objs, P.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, P.debug_flags, P.debug_counters);
 				waiting = false;

@@ -35,6 +35,8 @@ enum ProbeOp {
 constexpr size_t kLdsBudgetBytes = 160u * 1024u;
 // LDS bytes reserved for the grids' occupancy masks (shared by the waves of a workgroup)
 constexpr size_t kMaskBudgetBytes = 48u * 1024u;
+// walk batching (kernels.hip): lanes of a wave that must be waiting for a grid walk before one is run
+constexpr uint32_t kWalkBatchDefault = 32;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
 constexpr double kMaxRoughness = 512.0;
 // waves per workgroup of the grid instantiation (they share the LDS occupancy masks)

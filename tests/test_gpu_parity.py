@@ -525,6 +525,32 @@ def test_sample_split_is_bit_exact(gpu_ctx, small_mesh_scene):
         fb.close(), ds.close()
 
 
+def test_walk_batching_does_not_change_the_image(gpu_ctx, small_mesh_scene):
+    """Grid scenes: a lane whose ray enters a grid's box waits until enough lanes of its wave need a walk (kernels.hip,
+    RenderParams::walk_batch).  That is scheduling only — the closest hit is the lexicographic minimum of (distance,
+    object index) whatever the order — so every batch size must give the same frame, with one wave per tile (lane =
+    pixel) and with split sample ranges (lanes draw (pixel, sample) items from a pool) alike."""
+    import os
+
+    st = Settings(scenes.camera(160, 96), sample_count=24, bounce_limit=5, seed=77)
+    cam = st.camera_settings
+    tiles = generate_tiles(160, 96, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, small_mesh_scene)
+    fb = render.Framebuffer(gpu_ctx, 160, 96)
+    frames = {}
+    try:
+        for split in ("1", "3"):
+            for batch in ("1", "7", "32", "64", "1000"):
+                os.environ["RMD_SAMPLE_SPLIT"], os.environ["RMD_WALK_BATCH"] = split, batch
+                fb.zero()
+                render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+                frames[(split, batch)] = fb.download().tobytes()
+    finally:
+        os.environ.pop("RMD_SAMPLE_SPLIT", None), os.environ.pop("RMD_WALK_BATCH", None)
+    assert len(set(frames.values())) == 1
+    fb.close(), ds.close()
+
+
 def test_degenerate_scenes_and_frames(gpu_ctx, oracle):
     """Empty scene (every ray misses), 1x1 frame, a single 3x5 tile off the 8-pixel lattice."""
     from raymond_amd.scene import Scene
