@@ -111,21 +111,24 @@ typedef struct rmd_camera {
 	double fov_vert; /* degrees */
 	double position[3];
 	double focal_length;
-	double aperture_radius; /* > 0 selects generate_primary_ray_with_dof (trace.rs:335-360);
-	                           0 selects generate_primary_ray (:322-333), which is what the
-	                           reference's worker calls (:199).  Gated because with radius 0
-	                           the reference's rejection loop never terminates. */
+	double aperture_radius; /* CameraSettings.aperture_radius.  The reference's worker always calls the pinhole
+	                           generate_primary_ray (:199, :322-333) whatever this field holds — its thin-lens
+	                           generate_primary_ray_with_dof (:335-360) is never called — and so does this library
+	                           unless rmd_settings.flags carries RMD_RENDER_DOF (and the radius is > 0: with
+	                           radius 0 the reference's rejection loop never terminates). */
 } rmd_camera;
 
 #define RMD_MAX_BOUNCE_LIMIT 16u
 
 /* The part of Settings (src/trace.rs:42-55) the per-tile body reads, plus the
  * RNG definition the reference lacks (it uses the unseedable thread_rng). */
+#define RMD_RENDER_DOF 1u /* rmd_settings.flags: primary rays through generate_primary_ray_with_dof (an extension: the
+                             reference defines that function but its render loop never calls it) */
 typedef struct rmd_settings {
 	uint32_t bounce_limit; /* Settings.bounce_limit; trace() starts at depth 1 (:200,:235) */
 	uint32_t sample_begin; /* first sample index s of this pass                             */
 	uint32_t sample_count; /* number of consecutive samples to add per pixel               */
-	uint32_t _pad;
+	uint32_t flags;        /* 0 = the reference's behaviour; RMD_RENDER_DOF                 */
 	uint64_t seed; /* Philox key; see "RNG" below                                   */
 } rmd_settings;
 
@@ -158,6 +161,21 @@ rmd_status rmd_context_create_on_stream(int32_t device_ordinal, void *hip_stream
 void rmd_context_destroy(rmd_context *ctx);
 /* Text of the last failure on this context (or of the last failed context-less call when ctx = NULL). */
 const char *rmd_last_error(const rmd_context *ctx);
+
+/* Scheduling tunables of a context.  NONE of them changes a result — every setting renders the same frame bit for bit
+ * (tests/test_gpu_parity.py checks that) — they only move work between waves.  Defaults are read from the environment
+ * variable named beside each key ONCE, when the context is created; 0 / unset = the library's own choice. */
+enum {
+	RMD_TUNE_SAMPLE_SPLIT = 0, /* RMD_SAMPLE_SPLIT: waves a wave tile's sample range is split over (0 = automatic)  */
+	RMD_TUNE_WALK_BATCH = 1,   /* RMD_WALK_BATCH: lanes of a wave that wait for a grid walk before one is run        */
+	RMD_TUNE_MASK_BUDGET = 2,  /* RMD_MASK_BUDGET: LDS bytes for the grids' occupancy masks (read by rmd_scene_create) */
+	RMD_TUNE_GRID_MODE = 3,    /* RMD_GRID_MODE=wavefront -> 1: streaming pipeline for grid scenes; 0 = megakernel    */
+	RMD_TUNE_SCRATCH_CAP_MB = 4, /* RMD_SCRATCH_CAP_MB: cap of the per-sample scratch of split launches, MiB (0 = a quarter of HBM);
+	                              a launch whose samples do not fit runs as several passes                              */
+	RMD_TUNE_COUNT = 5
+};
+rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value);
+rmd_status rmd_context_get_tunable(const rmd_context *ctx, uint32_t key, int64_t *out_value);
 
 /* Uploads the object table and the grids to HBM.  Replaces the per-worker
  * `scene.clone()` (src/trace.rs:182-185): one resident copy per GPU. */

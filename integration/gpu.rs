@@ -41,7 +41,7 @@ pub struct rmd_grid_desc {
 #[repr(C)]
 pub struct rmd_camera { pub backbuffer_width: u32, pub backbuffer_height: u32, pub fov_vert: f64, pub position: [f64; 3], pub focal_length: f64, pub aperture_radius: f64 }
 #[repr(C)]
-pub struct rmd_settings { pub bounce_limit: u32, pub sample_begin: u32, pub sample_count: u32, _pad: u32, pub seed: u64 }
+pub struct rmd_settings { pub bounce_limit: u32, pub sample_begin: u32, pub sample_count: u32, pub flags: u32 /* 0, or RMD_RENDER_DOF = 1 */, pub seed: u64 }
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct rmd_tile_rect { pub left: u32, pub top: u32, pub width: u32, pub height: u32 }
@@ -57,7 +57,7 @@ extern "C" {
     fn rmd_scene_destroy(scene: *mut rmd_scene);
     fn rmd_framebuffer_alloc(ctx: *mut rmd_context, width: u32, height: u32, out: *mut *mut f64) -> i32;
     fn rmd_framebuffer_free(ctx: *mut rmd_context, dev: *mut f64) -> i32;
-    fn rmd_framebuffer_zero(ctx: *mut rmd_context, dev: *mut f64, n: usize) -> i32;
+    fn rmd_framebuffer_upload(ctx: *mut rmd_context, host: *const f64, dev: *mut f64, n: usize) -> i32;
     fn rmd_framebuffer_download(ctx: *mut rmd_context, dev: *const f64, host: *mut f64, n: usize) -> i32;
     fn rmd_render_tiles(ctx: *mut rmd_context, scene: *const rmd_scene, camera: *const rmd_camera, settings: *const rmd_settings,
                         tiles: *const rmd_tile_rect, n_tiles: u32, accum_dev: *mut f64) -> i32;
@@ -133,8 +133,16 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
     super::trace::push_tiles(&queue, &settings); // the 'gen_tiles loop of :142-173, moved into a function
 
     let thread_count = Arc::new(AtomicUsize::new(settings.worker_count));
+    // tiles a worker has popped and not yet finished or re-queued: a worker may only leave when the queue is empty AND this is 0
+    // (with one GPU call per batch the queue is momentarily empty between progressive passes while other workers hold the tiles)
+    let in_flight = Arc::new(AtomicUsize::new(0));
+    let (tw, th) = settings.tile_size;
+    let cs = &settings.camera_settings;
+    let n_tiles = ((cs.backbuffer_width + tw - 1) / tw) * ((cs.backbuffer_height + th - 1) / th);
+    // a quarter of a GPU's share per pop, so that every GPU gets work and the tail stays short (1080p: 2040 tiles, 8 GPUs -> 64)
+    let batch_size = ((n_tiles + settings.worker_count * 4 - 1) / (settings.worker_count * 4)).max(1);
     for gpu in 0..settings.worker_count {
-        let (queue, sender, thread_count) = (queue.clone(), sender.clone(), thread_count.clone());
+        let (queue, sender, thread_count, in_flight) = (queue.clone(), sender.clone(), thread_count.clone(), in_flight.clone());
         let (scene, settings) = (scene.clone(), settings.clone()); // :182-185
         thread::spawn(move || unsafe {
             let mut ctx = ptr::null_mut();
@@ -154,28 +162,43 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
             loop {
                 // a batch of tiles at the same sample count (was: one tile, `queue.try_pop()`, :189)
                 let mut batch: Vec<Tile> = Vec::new();
-                while batch.len() < 4096 {
+                while batch.len() < batch_size {
+                    in_flight.fetch_add(1, Ordering::AcqRel); // counted before the pop so that the sum never reads 0 while a tile is in hand
                     match queue.try_pop() {
-                        Some(t) => { if batch.first().map_or(true, |b: &Tile| b.sample_count == t.sample_count) { batch.push(t) } else { queue.push(t); break } }
-                        None => break,
+                        Some(t) => { if batch.first().map_or(true, |b: &Tile| b.sample_count == t.sample_count) { batch.push(t) } else { queue.push(t); in_flight.fetch_sub(1, Ordering::AcqRel); break } }
+                        None => { in_flight.fetch_sub(1, Ordering::AcqRel); break }
                     }
                 }
                 if batch.is_empty() {
+                    if in_flight.load(Ordering::Acquire) != 0 { thread::yield_now(); continue; } // other workers will re-queue their tiles
                     thread_count.fetch_sub(1, Ordering::Relaxed); // :191-193
                     break;
                 }
                 let begin = batch[0].sample_count;
                 let n = pass.min(settings.sample_count - begin);
                 let rects: Vec<rmd_tile_rect> = batch.iter().map(|t| rmd_tile_rect { left: t.left as u32, top: t.top as u32, width: t.width as u32, height: t.height as u32 }).collect();
-                let st = rmd_settings { bounce_limit: settings.bounce_limit as u32, sample_begin: begin as u32, sample_count: n as u32, _pad: 0, seed };
-                check(ctx, rmd_framebuffer_zero(ctx, fb, w * h * 3));
+                // flags: 0 — the reference's loop calls the pinhole generate_primary_ray whatever cam.aperture_radius holds (:199);
+                // RMD_RENDER_DOF (1) would opt into generate_primary_ray_with_dof, which the reference defines but never calls
+                let st = rmd_settings { bounce_limit: settings.bounce_limit as u32, sample_begin: begin as u32, sample_count: n as u32, flags: 0, seed };
+                // the tiles' running sums go up, the kernel adds samples begin..begin+n to them one by one (`+=` of :203, in sample
+                // order: progressive passes give the same bits as one pass), and the sums come back
+                for tile in &batch {
+                    for y in 0..tile.height {
+                        for x in 0..tile.width {
+                            let (p, v) = (((tile.left + x) + (tile.top + y) * w) * 3, tile.data[x + y * tile.width]);
+                            host[p] = v.x; host[p + 1] = v.y; host[p + 2] = v.z;
+                        }
+                    }
+                }
+                check(ctx, rmd_framebuffer_upload(ctx, host.as_ptr(), fb, w * h * 3));
                 check(ctx, rmd_render_tiles(ctx, dev_scene, &camera, &st, rects.as_ptr(), rects.len() as u32, fb)); // replaces :197-205
                 check(ctx, rmd_framebuffer_download(ctx, fb, host.as_mut_ptr(), w * h * 3));
+                let held = batch.len();
                 for mut tile in batch {
                     for y in 0..tile.height {
                         for x in 0..tile.width {
                             let p = ((tile.left + x) + (tile.top + y) * w) * 3;
-                            tile.data[x + y * tile.width] += Vector3::new(host[p], host[p + 1], host[p + 2]); // `+=` of :203, n samples at once
+                            tile.data[x + y * tile.width] = Vector3::new(host[p], host[p + 1], host[p + 2]);
                         }
                     }
                     tile.sample_count += n; // :207
@@ -186,6 +209,7 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
                         if settings.samples_per_iteration != 0 { sender.send(Message::TileProgressed(tile)).unwrap(); } // :217-219
                     }
                 }
+                in_flight.fetch_sub(held, Ordering::AcqRel); // after the re-queue: the queue and this counter are never both empty mid-render
             }
             rmd_framebuffer_free(ctx, fb);
             rmd_scene_destroy(dev_scene);

@@ -656,7 +656,7 @@ V3 sample_pixel(const Scene &scene, const rmd_camera &cam, const rmd_settings &s
 	tl_counters.c[K_SAMPLES]++;
 	Rng rng(st.seed, y * cam.backbuffer_width + x, s);
 	Ray primary;
-	if (cam.aperture_radius > 0.0) {
+	if ((st.flags & RMD_RENDER_DOF) && cam.aperture_radius > 0.0) { /* render_tiled itself only ever calls the pinhole generator (:199) */
 		bool ok = true;
 		primary = generate_primary_ray_with_dof(x, y, cam, rng, ok);
 		if (!ok) return v3(0.0, 0.0, 0.0);

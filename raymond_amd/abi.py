@@ -35,6 +35,8 @@ RMD_GEOM_PLANE, RMD_GEOM_SPHERE, RMD_GEOM_GRID = 0, 1, 2
 RMD_MAT_DIFFUSE, RMD_MAT_METAL, RMD_MAT_EMISSION = 0, 1, 2
 
 RMD_MAX_BOUNCE_LIMIT = 16
+RMD_RENDER_DOF = 1  # rmd_settings.flags
+(RMD_TUNE_SAMPLE_SPLIT, RMD_TUNE_WALK_BATCH, RMD_TUNE_MASK_BUDGET, RMD_TUNE_GRID_MODE, RMD_TUNE_SCRATCH_CAP_MB) = range(5)
 RMD_COMM_ID_BYTES = 128
 
 
@@ -92,7 +94,7 @@ class Settings(C.Structure):
         ("bounce_limit", C.c_uint32),
         ("sample_begin", C.c_uint32),
         ("sample_count", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("flags", C.c_uint32),
         ("seed", C.c_uint64),
     ]
 

@@ -44,6 +44,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 	ctx->device = device;
 	ctx->n_cus = (uint32_t)prop.multiProcessorCount;
 	ctx->wave_slots = (uint32_t)prop.multiProcessorCount * 16u; // both render kernels fit 4 waves per SIMD (<= 128 VGPRs)
+	ctx->hbm_bytes = (size_t)prop.totalGlobalMem;
 	if (own_stream) {
 		hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 		if (se != hipSuccess) {
@@ -53,6 +54,22 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->owns_stream = true;
 	} else {
 		ctx->stream = stream;
+	}
+	// environment hooks are read here, once; rmd_context_set_tunable changes them afterwards
+	{
+		auto env_int = [](const char *name) -> int64_t {
+			const char *v = std::getenv(name);
+			return v ? (int64_t)std::atoll(v) : 0;
+		};
+		ctx->tunable[RMD_TUNE_SAMPLE_SPLIT] = env_int("RMD_SAMPLE_SPLIT");
+		ctx->tunable[RMD_TUNE_WALK_BATCH] = env_int("RMD_WALK_BATCH");
+		ctx->tunable[RMD_TUNE_MASK_BUDGET] = env_int("RMD_MASK_BUDGET");
+		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
+		const char *mode = std::getenv("RMD_GRID_MODE");
+		ctx->tunable[RMD_TUNE_GRID_MODE] = (mode && std::strcmp(mode, "wavefront") == 0) ? 1 : 0;
+#if RMD_DIAG
+		ctx->debug_flags = (uint32_t)env_int("RMD_DEBUG"); // DIAG builds only: 1 | 2 are timing ablations that change results, 8 | 16 count events
+#endif
 	}
 	if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
 		rmd_context_destroy(ctx);
@@ -124,7 +141,7 @@ rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text) {
 }
 
 // generate_primary_ray's loop-invariant terms (src/trace.rs:323-330), evaluated with the host libm
-RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *st) {
+RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *st) {
 	const double PI = 3.14159265358979323846;
 	RenderParams P;
 	std::memset(&P, 0, sizeof(P));
@@ -143,10 +160,12 @@ RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rm
 	P.n_grids = scene ? scene->n_grids : 0;
 	P.mask_words_total = scene ? scene->mask_words_total : 0;
 	P.key0 = (uint32_t)st->seed, P.key1 = (uint32_t)(st->seed >> 32);
-	P.use_dof = cam->aperture_radius > 0.0 ? 1u : 0u;
+	P.use_dof = ((st->flags & RMD_RENDER_DOF) && cam->aperture_radius > 0.0) ? 1u : 0u; // off by default, as in the reference's loop (:199)
 	P.walk_batch = rmd::kWalkBatchDefault;
-	if (const char *wb = std::getenv("RMD_WALK_BATCH")) P.walk_batch = (uint32_t)std::atoi(wb); // test hook: any value gives the same image
-	if (const char *dbg = std::getenv("RMD_DEBUG")) P.debug_flags = (uint32_t)std::atoi(dbg); // timing-only ablations; results are wrong
+	if (ctx && ctx->tunable[RMD_TUNE_WALK_BATCH] > 0) P.walk_batch = (uint32_t)ctx->tunable[RMD_TUNE_WALK_BATCH]; // any value gives the same image
+#if RMD_DIAG
+	if (ctx) P.debug_flags = ctx->debug_flags;
+#endif
 	return P;
 }
 
@@ -287,12 +306,16 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		// occupancy bitmask for LDS: bit i covers cells [i << shift, (i+1) << shift); only up to the last non-empty cell
 		const uint64_t covered = any_nonempty ? last_nonempty + 1 : 0;
 		size_t budget_bytes = rmd::kMaskBudgetBytes;
-		if (const char *env = std::getenv("RMD_MASK_BUDGET")) budget_bytes = (size_t)std::atol(env); // test hook: force coarse masks
+		if (ctx->tunable[RMD_TUNE_MASK_BUDGET] > 0) budget_bytes = (size_t)ctx->tunable[RMD_TUNE_MASK_BUDGET]; // forces coarser masks
 		if (budget_bytes < 64) budget_bytes = 64;
 		if (budget_bytes > rmd::kMaskBudgetBytes) budget_bytes = rmd::kMaskBudgetBytes;
 		const size_t budget_words = budget_bytes / 4 / n_grids;
+		if (budget_words < 2) { // one data word + the all-zero pad word is the smallest mask
+			rmd_scene_destroy(sc);
+			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: too many grids for the LDS occupancy-mask budget");
+		}
 		uint32_t shift = 0;
-		while (((covered >> shift) + 31) / 32 + 1 > budget_words) shift++;
+		while (shift < 63 && ((covered >> shift) + 31) / 32 + 1 > budget_words) shift++;
 		const uint64_t bits = covered ? ((covered - 1) >> shift) + 1 : 0;
 		std::vector<uint32_t> mask((size_t)((bits + 31) / 32) + 1, 0u); // + one all-zero word: indices past the mask read it
 		for (uint64_t c = 0; c < covered; c++)
@@ -378,8 +401,8 @@ rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *
 // unsplit launch (tests/test_gpu_parity.py::test_sample_split_is_bit_exact).  RMD_SAMPLE_SPLIT=K forces K.
 static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_wave_tiles, uint32_t sample_count) {
 	uint32_t k = 1;
-	if (const char *env = std::getenv("RMD_SAMPLE_SPLIT")) {
-		k = (uint32_t)std::atoi(env);
+	if (ctx->tunable[RMD_TUNE_SAMPLE_SPLIT] > 0) {
+		k = (uint32_t)ctx->tunable[RMD_TUNE_SAMPLE_SPLIT];
 	} else if (n_wave_tiles != 0) {
 		if (has_grid) {
 			// mesh tiles cost ~10x wall tiles, so their waves form a long tail even on a full 1080p frame (measured: 2-way
@@ -404,7 +427,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	if (rmd_status s = check_render_args(ctx, scene, camera, settings)) return s;
 	if (!accum_dev || (n_tiles && !tiles)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_render_tiles: null tiles/accum pointer");
 	if (rmd_status s = prepare_wave_tiles(ctx, camera, tiles, n_tiles)) return s;
-	rmd::RenderParams P = rmd::make_params(scene, camera, settings);
+	rmd::RenderParams P = rmd::make_params(ctx, scene, camera, settings);
 	P.n_work = ctx->n_wave_tiles;
 	if (P.debug_flags & 24u) {
 		if (!ctx->d_debug_counters) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_debug_counters, 16 * sizeof(unsigned long long)));
@@ -413,8 +436,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	}
 	// Scenes with grids can also be evaluated by the streaming pipeline of wavefront.hip (RMD_GRID_MODE=wavefront):
 	// same result bit for bit, different schedule.
-	const char *mode = std::getenv("RMD_GRID_MODE");
-	if (scene->n_grids != 0 && mode && std::strcmp(mode, "wavefront") == 0 && !(P.debug_flags & 24u) && (uint64_t)P.n_work * 64u < 0x7FFFFFFFull) {
+	if (scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 1 && !(P.debug_flags & 24u) && (uint64_t)P.n_work * 64u < 0x7FFFFFFFull) {
 		const size_t need = rmd::wavefront_workspace_bytes(P.n_work);
 		if (need > ctx->wavefront_ws_bytes) {
 			if (ctx->d_wavefront_ws) RMD_HIP(ctx, hipFree(ctx->d_wavefront_ws));
@@ -429,11 +451,13 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		return RMD_OK;
 	}
 	const uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
-	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes; cap it at 8 GiB
+	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes.  It may take a quarter of the
+	// device's HBM (72 GiB of 288: the whole C3 frame at 500 spp is 24.9 GB, one launch); what does not fit runs as several passes
 	uint32_t per_pass = P.sample_count;
 	if (split > 1u) {
 		const size_t bytes_per_sample = (size_t)P.n_work * 64u * 3u * sizeof(double);
-		const size_t cap = (size_t)8 << 30;
+		size_t cap = ctx->hbm_bytes / 4;
+		if (ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] > 0) cap = (size_t)ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] << 20;
 		if (bytes_per_sample * per_pass > cap) per_pass = (uint32_t)(cap / bytes_per_sample);
 		if (per_pass < 8u) per_pass = 8u;
 		const size_t need = bytes_per_sample * per_pass;
@@ -445,10 +469,10 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		}
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-	for (uint32_t done = 0; done < settings->sample_count || done == 0; done += per_pass) {
+	for (uint64_t done = 0; done < settings->sample_count || done == 0; done += per_pass) { // 64-bit: sample_count may be close to 2^32
 		rmd::RenderParams Q = P;
-		Q.sample_begin = settings->sample_begin + done;
-		Q.sample_count = settings->sample_count - done < per_pass ? settings->sample_count - done : per_pass;
+		Q.sample_begin = settings->sample_begin + (uint32_t)done;
+		Q.sample_count = settings->sample_count - done < per_pass ? (uint32_t)(settings->sample_count - done) : per_pass;
 		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
 		Q.sample_buf = ctx->d_sample_buf;
 		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev));
@@ -467,6 +491,19 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu tests=%llu chunks=%llu | main_iterations=%llu live_lanes=%llu lanes_with_ray=%llu shade_passes=%llu shaded_lanes=%llu\n",
 			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[14], h[13]);
 	}
+	return RMD_OK;
+}
+
+rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value) {
+	if (!ctx) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: null context");
+	if (key >= RMD_TUNE_COUNT || value < 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: unknown key or negative value");
+	if (key == RMD_TUNE_GRID_MODE && value > 1) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: grid mode is 0 or 1");
+	ctx->tunable[key] = value;
+	return RMD_OK;
+}
+rmd_status rmd_context_get_tunable(const rmd_context *ctx, uint32_t key, int64_t *out_value) {
+	if (!ctx || !out_value || key >= RMD_TUNE_COUNT) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_get_tunable: bad argument");
+	*out_value = ctx->tunable[key];
 	return RMD_OK;
 }
 

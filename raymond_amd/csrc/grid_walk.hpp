@@ -160,7 +160,12 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	int32_t dix = 0, diy = 0, diz = 0;
 	uint32_t idx = 0, remx = 1, remy = 1, remz = 1;
 	double tmx = 0.0, tmy = 0.0, tmz = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
-	if (want && !(debug_flags & 2u)) {
+#if RMD_DIAG
+	const bool skip_walk = (debug_flags & 2u) != 0u, skip_tests = (debug_flags & 1u) != 0u; // timing ablations: wrong results, DIAG builds only
+#else
+	constexpr bool skip_walk = false, skip_tests = false;
+#endif
+	if (want && !skip_walk) {
 		// acc_grid.rs:90-125
 		V3 bmin = ld3(g.bbox_min);
 		double t_outer;
@@ -233,8 +238,11 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			// axis' {t_max += t_delta; counter -= 1; index += stride} under its mask — 12 vector instructions, no branches
 			// (the compiler's version re-evaluates a compare, routes the stride through a select and branches around two blocks).
 			{
+				// exec is saved in %[sv] and restored by the last instruction; the scalar mask arithmetic overwrites SCC and VCC
+				// (both clobbered), and the block is volatile so that it is neither duplicated nor moved across the exec-dependent
+				// code around it.
 				unsigned long long m_xy, m_xz, saved;
-				asm("v_cmp_lt_f64 %[mxy], %[tmx], %[tmy]\n\t"
+				asm volatile("v_cmp_lt_f64 %[mxy], %[tmx], %[tmy]\n\t"
 				    "v_cmp_lt_f64 %[mxz], %[tmx], %[tmz]\n\t"
 				    "v_cmp_lt_f64 vcc, %[tmy], %[tmz]\n\t"
 				    "s_mov_b64 %[sv], exec\n\t"
@@ -257,7 +265,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				    : [tmx] "+v"(tmx), [tmy] "+v"(tmy), [tmz] "+v"(tmz), [rx] "+v"(remx), [ry] "+v"(remy), [rz] "+v"(remz), [idx] "+v"(idx),
 				      [mxy] "=&s"(m_xy), [mxz] "=&s"(m_xz), [sv] "=&s"(saved)
 				    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [dix] "v"(dix), [diy] "v"(diy), [diz] "v"(diz)
-				    : "vcc");
+				    : "vcc", "scc");
 			}
 #else
 			const bool lt_xy = tmx < tmy, lt_xz = tmx < tmz, lt_yz = tmy < tmz;
@@ -300,7 +308,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				c_first[m] = (uint32_t)e, c_count[m] = (uint32_t)(e >> 32);
 			}
 #pragma unroll
-			for (uint32_t m = 0; m < kWalkCand; m++) c_count[m] = (m < n_cand && !(debug_flags & 1u)) ? c_count[m] : 0u;
+			for (uint32_t m = 0; m < kWalkCand; m++) c_count[m] = (m < n_cand && !skip_tests) ? c_count[m] : 0u;
 		}
 		RMD_STAMP(2)
 

@@ -33,9 +33,14 @@ struct rmd_context {
 	size_t sample_buf_bytes = 0;
 	uint32_t wave_slots = 0; // CUs x waves per CU the render kernels can keep resident
 	uint32_t n_cus = 0;
+	size_t hbm_bytes = 0; // totalGlobalMem of the device
 	void *d_wavefront_ws = nullptr; // path state of the streaming mode (wavefront.hip)
 	size_t wavefront_ws_bytes = 0;
 	unsigned long long *d_debug_counters = nullptr; // walk diagnostics (DIAG builds, RMD_DEBUG=8|16)
+	// Tunables (include/raymond_hip.h: rmd_context_set_tunable).  Defaults come from the environment, read ONCE when the
+	// context is created; none of them changes a result.
+	int64_t tunable[RMD_TUNE_COUNT] = {};
+	uint32_t debug_flags = 0; // RMD_DEBUG, honoured by DIAG builds only
 };
 
 struct rmd_scene {

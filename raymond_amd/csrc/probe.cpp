@@ -9,7 +9,7 @@
 #include "launch.hpp"
 
 namespace rmd {
-RenderParams make_params(const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *st);
+RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *st);
 }
 
 namespace {
@@ -188,7 +188,7 @@ rmd_status rmd_probe_primary_ray(rmd_context *ctx, size_t n, const rmd_camera *c
 	if (!cam || !xy2) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "probe: null argument");
 	rmd_settings st;
 	std::memset(&st, 0, sizeof(st));
-	rmd::RenderParams P = rmd::make_params(nullptr, cam, &st);
+	rmd::RenderParams P = rmd::make_params(ctx, nullptr, cam, &st);
 	std::vector<double> xy = widen(xy2, n * 2), out;
 	if (rmd_status s = run_probe(ctx, rmd::PROBE_PRIMARY_RAY, n, {{xy.data(), 2}, {u2, 2}}, 6, out, &P)) return s;
 	unpack(out, 6, 0, 6, ray6, n);
@@ -246,7 +246,7 @@ rmd_status rmd_probe_trace_samples(rmd_context *ctx, const rmd_scene *scene, con
 		RMD_HIP(ctx, hipMemsetAsync(dps.p, 0, n_pad * RMD_PATH_STRIDE * sizeof(uint32_t), ctx->stream));
 		RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	rmd::RenderParams P = rmd::make_params(scene, cam, settings);
+	rmd::RenderParams P = rmd::make_params(ctx, scene, cam, settings);
 	P.n_work = (uint32_t)n;
 	RMD_HIP(ctx, rmd::launch_render_list(ctx->stream, P, scene->d_objects, scene->d_grids, (const rmd::ListWork *)dl.p, (double *)drgb.p,
 	                                     (int32_t *)dpo.p, (uint32_t *)dps.p));

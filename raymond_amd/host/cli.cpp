@@ -89,7 +89,7 @@ int main(int argc, char **argv) {
 				if (!std::strcmp(argv[i], "--raw")) raw = argv[i + 1];
 				else if (!std::strcmp(argv[i], "--gpus")) st.worker_count = std::atoi(argv[i + 1]);
 				else if (!std::strcmp(argv[i], "--spi")) st.samples_per_iteration = std::atoi(argv[i + 1]);
-				else if (!std::strcmp(argv[i], "--aperture")) st.camera_settings.aperture_radius = std::atof(argv[i + 1]);
+				else if (!std::strcmp(argv[i], "--aperture")) st.camera_settings.aperture_radius = std::atof(argv[i + 1]), st.use_dof = true;
 			}
 			Scene scene;
 			if (what == "spheres") scene = reflective_spheres();

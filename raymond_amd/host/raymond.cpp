@@ -109,6 +109,7 @@ struct TaskHandle::Shared {
 	std::deque<Tile> queue;      // MsQueue<Tile> (:138)
 	std::deque<Message> channel; // mpsc::channel (:139)
 	size_t alive = 0;            // alive_thread_count (:175)
+	size_t in_flight = 0;        // tiles popped by a worker and not yet finished or re-queued
 	std::string error;
 };
 
@@ -161,18 +162,25 @@ void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene
 		cam.backbuffer_width = (uint32_t)W, cam.backbuffer_height = (uint32_t)H, cam.fov_vert = st.camera_settings.fov_vert;
 		for (int a = 0; a < 3; a++) cam.position[a] = st.camera_settings.transform.position[a];
 		cam.focal_length = st.camera_settings.focal_length, cam.aperture_radius = st.camera_settings.aperture_radius;
+		const uint32_t flags = st.use_dof ? RMD_RENDER_DOF : 0u; // the reference's loop is pinhole-only (:199); the thin lens is opt-in
 		std::vector<double> host(W * H * 3);
 		const size_t step = st.samples_per_iteration ? st.samples_per_iteration : st.sample_count;
 		for (;;) {
 			std::vector<Tile> mine;
 			{
-				std::lock_guard<std::mutex> lock(sh->m);
-				while (!sh->queue.empty() && mine.size() < batch) { // try_pop (:189)
+				// try_pop (:189).  The reference's worker leaves as soon as the queue is empty (:191-194); with one GPU call
+				// per batch a queue that is only momentarily empty — the other workers hold every tile and will re-queue them
+				// for the next progressive pass — would collapse the pool to one GPU, so a worker leaves only when no tile is
+				// queued AND none is in flight.
+				std::unique_lock<std::mutex> lock(sh->m);
+				sh->cv.wait(lock, [&] { return !sh->queue.empty() || sh->in_flight == 0 || !sh->error.empty(); });
+				while (sh->error.empty() && !sh->queue.empty() && mine.size() < batch) {
 					mine.push_back(std::move(sh->queue.front()));
 					sh->queue.pop_front();
 				}
+				sh->in_flight += mine.size();
 			}
-			if (mine.empty()) break; // None -> the worker exits (:191-194)
+			if (mine.empty()) break;
 			// tiles of one batch may be at different sample counts; group by sample_count
 			std::map<size_t, std::vector<size_t>> by_count;
 			for (size_t i = 0; i < mine.size(); i++) by_count[mine[i].sample_count].push_back(i);
@@ -190,7 +198,7 @@ void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene
 				check(rmd_framebuffer_upload(ctx, host.data(), fb, host.size()), ctx, "rmd_framebuffer_upload");
 				rmd_settings rs;
 				std::memset(&rs, 0, sizeof(rs));
-				rs.bounce_limit = (uint32_t)st.bounce_limit, rs.sample_begin = (uint32_t)begin, rs.sample_count = (uint32_t)n, rs.seed = st.seed;
+				rs.bounce_limit = (uint32_t)st.bounce_limit, rs.sample_begin = (uint32_t)begin, rs.sample_count = (uint32_t)n, rs.seed = st.seed, rs.flags = flags;
 				check(rmd_render_tiles(ctx, dscene, &cam, &rs, rects.data(), (uint32_t)rects.size(), fb), ctx, "rmd_render_tiles");
 				check(rmd_framebuffer_download(ctx, fb, host.data(), host.size()), ctx, "rmd_framebuffer_download");
 				for (size_t i : grp.second) {
@@ -202,6 +210,7 @@ void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene
 				}
 			}
 			std::lock_guard<std::mutex> lock(sh->m);
+			sh->in_flight -= mine.size();
 			for (Tile &t : mine) {
 				if (t.sample_count == st.sample_count) { // :211-212
 					sh->channel.push_back(Message{Message::TileFinished, std::move(t)});
@@ -215,7 +224,8 @@ void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene
 		}
 	} catch (const std::exception &e) {
 		std::lock_guard<std::mutex> lock(sh->m);
-		if (sh->error.empty()) sh->error = e.what();
+		if (sh->error.empty()) sh->error = e.what(); // the waiting workers see it and leave
+		sh->cv.notify_all();
 	}
 	if (fb) rmd_framebuffer_free(ctx, fb);
 	rmd_scene_destroy(dscene);

@@ -118,6 +118,7 @@ struct Settings { // src/trace.rs:42-55 (+ the RNG seed the reference lacks)
 	std::pair<size_t, size_t> tile_size{32, 32};
 	size_t bounce_limit = 5;
 	uint64_t seed = 0x5EED0001ull;
+	bool use_dof = false; // opt-in: generate_primary_ray_with_dof (src/trace.rs:335-360); the reference's loop never calls it (:199)
 };
 
 struct Tile { // core/src/tile.rs:7-14

@@ -43,6 +43,15 @@ class Context:
     def check(self, status):
         _lib.check(status, self.handle)
 
+    def set_tunable(self, key, value):
+        """rmd_context_set_tunable: scheduling knobs (abi.RMD_TUNE_*); no setting changes a result.  0 = the library's choice."""
+        self.check(self.L.rmd_context_set_tunable(self.handle, key, int(value)))
+
+    def get_tunable(self, key):
+        v = C.c_int64()
+        self.check(self.L.rmd_context_get_tunable(self.handle, key, C.byref(v)))
+        return v.value
+
     def synchronize(self):
         self.check(self.L.rmd_context_synchronize(self.handle))
 

@@ -243,7 +243,7 @@ class Settings:
     """src/trace.rs:42-55 plus the RNG seed the reference lacks."""
 
     def __init__(self, camera_settings, sample_count, tile_size=(32, 32), bounce_limit=5, samples_per_iteration=0,
-                 worker_count=None, seed=0x5EED0001):
+                 worker_count=None, seed=0x5EED0001, use_dof=False):
         self.camera_settings = camera_settings
         self.sample_count = int(sample_count)
         self.tile_size = (int(tile_size[0]), int(tile_size[1]))
@@ -251,6 +251,9 @@ class Settings:
         self.samples_per_iteration = int(samples_per_iteration)
         self.worker_count = worker_count  # number of GPUs (contexts) here; None = 1
         self.seed = int(seed)
+        # The reference's loop always calls the pinhole generate_primary_ray (src/trace.rs:199) whatever
+        # camera_settings.aperture_radius holds; use_dof=True opts into generate_primary_ray_with_dof (:335-360).
+        self.use_dof = bool(use_dof)
 
     def pod(self, sample_begin=0, sample_count=None):
         s = abi.Settings()
@@ -258,6 +261,7 @@ class Settings:
         s.sample_begin = int(sample_begin)
         s.sample_count = self.sample_count if sample_count is None else int(sample_count)
         s.seed = self.seed
+        s.flags = abi.RMD_RENDER_DOF if self.use_dof else 0
         return s
 
 

@@ -131,4 +131,5 @@ CONFIGS = {
 
 def config_settings(name, spp=None):
     _, w, h, s, b, ap = CONFIGS[name]
-    return Settings(camera(w, h, ap), sample_count=s if spp is None else spp, tile_size=(32, 32), bounce_limit=b, seed=SEED)
+    return Settings(camera(w, h, ap), sample_count=s if spp is None else spp, tile_size=(32, 32), bounce_limit=b, seed=SEED,
+                    use_dof=ap > 0.0)  # C5 names the thin lens explicitly; the reference's own loop never uses it

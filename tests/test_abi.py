@@ -56,7 +56,7 @@ int main(void) {
   S(rmd_grid_desc); O(rmd_grid_desc, bbox_max); O(rmd_grid_desc, resolution); O(rmd_grid_desc, cell_size); O(rmd_grid_desc, cells);
   O(rmd_grid_desc, n_cells); O(rmd_grid_desc, mapping_table); O(rmd_grid_desc, n_mapping); O(rmd_grid_desc, tri_pos); O(rmd_grid_desc, tri_nrm); O(rmd_grid_desc, n_tris);
   S(rmd_camera); O(rmd_camera, fov_vert); O(rmd_camera, position); O(rmd_camera, focal_length); O(rmd_camera, aperture_radius);
-  S(rmd_settings); O(rmd_settings, sample_begin); O(rmd_settings, sample_count); O(rmd_settings, seed);
+  S(rmd_settings); O(rmd_settings, sample_begin); O(rmd_settings, sample_count); O(rmd_settings, flags); O(rmd_settings, seed);
   S(rmd_tile_rect); O(rmd_tile_rect, height);
   return 0; }
 """

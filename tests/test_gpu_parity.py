@@ -19,7 +19,7 @@ multiplies forward into a throughput instead of applying them on the way back up
 import numpy as np
 import pytest
 
-from raymond_amd import probe, render, scenes
+from raymond_amd import abi, probe, render, scenes
 from raymond_amd.scene import Settings, generate_tiles
 
 pytestmark = pytest.mark.gpu
@@ -337,7 +337,7 @@ def test_per_sample_mesh(gpu_ctx, oracle, small_mesh_scene):
 
 def test_per_sample_dof_and_deep_bounces(gpu_ctx, oracle, small_mesh_scene):
     """Config-5 style thin lens (rejection-sampled aperture, variable draw count, Q12) and bounce_limit 8 (config 4)."""
-    st = Settings(scenes.camera(480, 270, aperture_radius=0.5), sample_count=1, bounce_limit=8, seed=scenes.SEED + 5)
+    st = Settings(scenes.camera(480, 270, aperture_radius=0.5), sample_count=1, bounce_limit=8, seed=scenes.SEED + 5, use_dof=True)
     same_path, close, drgb, orgb = _per_sample(gpu_ctx, oracle, small_mesh_scene, st, 12000, 31)
     assert close[same_path].all()
     assert same_path.mean() >= 0.999 and close.mean() >= 0.999
@@ -507,18 +507,15 @@ def test_sample_split_is_bit_exact(gpu_ctx, small_mesh_scene):
         ds = render.DeviceScene(gpu_ctx, scene)
         fb = render.Framebuffer(gpu_ctx, 200, 120)
         results = {}
-        for k in ("1", "2", "4", "5", None):  # None = automatic choice (this small frame splits)
-            if k is None:
-                os.environ.pop("RMD_SAMPLE_SPLIT", None)
-            else:
-                os.environ["RMD_SAMPLE_SPLIT"] = k
+        for k in (1, 2, 4, 5, 0):  # 0 = automatic choice (this small frame splits)
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, k)
             try:
                 fb.upload(base)
                 render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
                 results[k] = fb.download()
             finally:
-                os.environ.pop("RMD_SAMPLE_SPLIT", None)
-        ref = results["1"]
+                gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0)
+        ref = results[1]
         assert (ref != base).any()
         for k, img in results.items():
             assert img.tobytes() == ref.tobytes(), "split %s differs" % k
@@ -539,14 +536,14 @@ def test_walk_batching_does_not_change_the_image(gpu_ctx, small_mesh_scene):
     fb = render.Framebuffer(gpu_ctx, 160, 96)
     frames = {}
     try:
-        for split in ("1", "3"):
-            for batch in ("1", "7", "32", "64", "1000"):
-                os.environ["RMD_SAMPLE_SPLIT"], os.environ["RMD_WALK_BATCH"] = split, batch
+        for split in (1, 3):
+            for batch in (1, 7, 32, 64, 1000):
+                gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), gpu_ctx.set_tunable(abi.RMD_TUNE_WALK_BATCH, batch)
                 fb.zero()
                 render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
                 frames[(split, batch)] = fb.download().tobytes()
     finally:
-        os.environ.pop("RMD_SAMPLE_SPLIT", None), os.environ.pop("RMD_WALK_BATCH", None)
+        gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_WALK_BATCH, 0)
     assert len(set(frames.values())) == 1
     fb.close(), ds.close()
 
@@ -605,13 +602,12 @@ def test_two_grids_and_coarse_masks(gpu_ctx, oracle):
     smp = rng.integers(0, 1000, n).astype(np.uint32)
     osc = oracle.OracleScene(sc)
     orgb = osc.trace_samples(cam, st, xy, smp)
-    for budget in (None, "256"):
-        if budget:
-            os.environ["RMD_MASK_BUDGET"] = budget
+    for budget in (None, 256):
+        gpu_ctx.set_tunable(abi.RMD_TUNE_MASK_BUDGET, budget or 0)
         try:
             ds = render.DeviceScene(gpu_ctx, sc)
         finally:
-            os.environ.pop("RMD_MASK_BUDGET", None)
+            gpu_ctx.set_tunable(abi.RMD_TUNE_MASK_BUDGET, 0)
         drgb, dpo, dps = probe.trace_samples(gpu_ctx, ds, cam, st, xy, smp, paths=True)
         close = rel_close(drgb, orgb, 1e-9).all(axis=1)
         assert close.mean() >= 0.999, (budget, close.mean())
@@ -637,7 +633,7 @@ def test_wavefront_mode_is_bit_identical(gpu_ctx, small_mesh_scene):
 
     cases = [
         (Settings(scenes.camera(200, 120), sample_count=9, bounce_limit=5, seed=5), 0, 9),
-        (Settings(scenes.camera(200, 120, aperture_radius=0.5), sample_count=6, bounce_limit=8, seed=6), 3, 6),
+        (Settings(scenes.camera(200, 120, aperture_radius=0.5), sample_count=6, bounce_limit=8, seed=6, use_dof=True), 3, 6),
         (Settings(scenes.camera(64, 40), sample_count=4, bounce_limit=0, seed=7), 0, 4),
         (Settings(scenes.camera(64, 40), sample_count=5, bounce_limit=1, seed=8), 0, 5),
     ]
@@ -650,13 +646,13 @@ def test_wavefront_mode_is_bit_identical(gpu_ctx, small_mesh_scene):
         fb = render.Framebuffer(gpu_ctx, W, H)
         out = {}
         for mode in ("megakernel", "wavefront"):
-            os.environ["RMD_GRID_MODE"] = mode
+            gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, 1 if mode == "wavefront" else 0)
             try:
                 fb.upload(base)
                 render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, begin, count)
                 out[mode] = fb.download()
             finally:
-                os.environ.pop("RMD_GRID_MODE", None)
+                gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, 0)
         assert out["wavefront"].tobytes() == out["megakernel"].tobytes()
         if st.bounce_limit:
             assert (out["megakernel"] != base).any()
