@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (default: the config's)")
-    ap.add_argument("--roofline-spp", type=int, default=50, help="spp of the C3 roofline leg")
+    ap.add_argument("--roofline-spp", type=int, default=None, help="spp of the C3 roofline leg (default: the config's 500)")
+    ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = calibrate to ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
@@ -83,14 +84,28 @@ def usable_cpus():
     return n, quota
 
 
-def load_traffic(name):
-    """Measured HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
+def load_traffic(name, spp):
+    """Measured L2<->fabric bytes of one launch of workload `name` at `spp` samples per pixel, from the committed rocprofv3
+    --pmc passes (profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes, gfx950 corrections applied), or
+    None when no pass was collected at that spp."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         entry = json.load(f).get(name)
-    return entry["bytes_per_launch"] if entry else None
+    if not entry or entry.get("spp") != spp:
+        return None
+    return entry["bytes_per_launch"]
+
+
+def load_valu(name):
+    """What bounds a VALU-bound launch, from the committed SQ counter pass (profiles/pmc_latest.json, written by
+    tools/pmc_summary.py --json): issue-slot occupancy of the vector ALU, lane utilisation, wave instructions per sample."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(name)
 
 
 def main():
@@ -226,29 +241,52 @@ def main():
         if bps is None:
             bps = 24.0 / spp
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
-        out["kernel"] = {"name": "rmd::render_kernel<%s>" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else ("0, false" if world == 1 else "1, false")),  # <MODE, GRID> as rocprofv3 prints it; a shard is rendered with split samples (MODE 1) "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]),
-                         "checksum": main_run["checksum"]}
-        out["roofline_%s" % name.lower()] = {
+        # <MODE, GRID> as rocprofv3 prints it; a shard is rendered with split samples (MODE 1)
+        kname = "rmd::render_kernel<%s>" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else ("0, false" if world == 1 else "1, false"))
+        out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"]}
+        traffic = load_traffic(name, spp) if world == 1 else None
+        rl = {
             "bound": "hbm", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": load_traffic(name), "bytes_per_sample": bps,
-            "note": "FP64-VALU bound workload (8-object scene lives in LDS/SGPRs); HBM traffic is the framebuffer only" if name == "C2" else "",
+            "traffic": traffic, "bytes_per_sample": bps, "avg_ms": round(avg_ms, 3),
         }
+        if traffic is not None:
+            rl["measured_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 3)
+            rl["measured_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if name == "C2":
+            # the real bound of this workload: FP64 vector-ALU issue (the 8-object scene lives in LDS/SGPRs, HBM sees the framebuffer only)
+            rl["note"] = "VALU-issue bound, not HBM bound: see `valu`"
+            v = load_valu("C2")
+            if v:
+                rl["valu"] = v
+        out["roofline_%s" % name.lower()] = rl
 
     # roofline leg: the traversal on the ~100k-triangle mesh (config C3, reduced spp; throughput is spp-independent)
     if not args.no_roofline_leg and world == 1:
-        rspp = args.roofline_spp
-        rr = run_workload("C3", rspp, 3, 1, reduce=False)
+        rspp = args.roofline_spp if args.roofline_spp is not None else scenes.CONFIGS["C3"][3]
+        rr = run_workload("C3", rspp, args.roofline_steps, 1, reduce=False)
         counters = load_counters()
         bps = algorithmic_bytes_per_sample("C3", rspp, counters)
         avg_ms = sum(rr["kernel_ms"]) / len(rr["kernel_ms"])
         ach = bps * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9
+        traffic = load_traffic("C3", rspp)
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": load_traffic("C3"),
-            "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces" % rspp,
-            "kernel": "rmd::render_kernel<1, true>", "avg_ms": round(avg_ms, 3),
-            "bytes_per_sample": round(bps, 2), "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
+            "traffic": traffic,
+            "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch" % rspp,
+            "kernel": "rmd::render_kernel<1, true> + rmd::sum_kernel", "avg_ms": round(avg_ms, 3), "launch_ms": [round(v, 3) for v in rr["kernel_ms"]],
+            "bytes_per_sample": round(bps, 2), "bytes_per_launch": bps * rr["samples_per_step"],
+            "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
+            "how": "achieved = algorithmic bytes per launch (8 B x cells visited + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
+                   "oracle counters in tests/golden/work_counters.json, + 24 B/pixel) / mean launch duration from HIP events on the launch stream; "
+                   "profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true> + sum_kernel over the same launches",
         }
+        if traffic is not None:
+            # L2<->fabric bytes per launch by PMC (upper bound on HBM bytes: Infinity-Cache hits are included)
+            out["roofline"]["measured_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 3)
+            out["roofline"]["measured_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        v = load_valu("C3")
+        if v:
+            out["roofline"]["valu"] = v
     elif rank == 0:
         out["roofline"] = out.get("roofline_%s" % name.lower())
 

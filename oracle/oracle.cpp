@@ -20,7 +20,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -680,10 +684,132 @@ Triangle tri_from(const double *pos9, const double *nrm9) {
 	return t;
 }
 
+/* ------------------------------------------------------------------ Mesh (core/src/geometry/mesh.rs) */
+/* str::split_whitespace */
+std::vector<std::string> split_ws(const std::string &line) {
+	std::vector<std::string> out;
+	size_t i = 0;
+	while (i < line.size()) {
+		while (i < line.size() && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r' || line[i] == '\n' || line[i] == '\f' || line[i] == '\v')) i++;
+		size_t j = i;
+		while (j < line.size() && !(line[j] == ' ' || line[j] == '\t' || line[j] == '\r' || line[j] == '\n' || line[j] == '\f' || line[j] == '\v')) j++;
+		if (j > i) out.push_back(line.substr(i, j - i));
+		i = j;
+	}
+	return out;
+}
+/* str::parse::<f64>(): decimal notation with optional exponent, "inf" / "infinity" / "nan" in any case, the whole token,
+ * correctly rounded — which glibc's strtod is too; hexadecimal floats are not Rust syntax. */
+bool parse_f64(const std::string &t, double &out) {
+	if (t.empty() || t.find_first_of("xX") != std::string::npos) return false;
+	for (char c : t)
+		if (c == '(' || c == ')') return false; /* strtod's "nan(...)" form */
+	char *end = nullptr;
+	out = std::strtod(t.c_str(), &end);
+	return end == t.c_str() + t.size();
+}
+/* str::parse::<u32>() / ::<usize>(): optional '+', decimal digits only, no overflow */
+bool parse_uint(const std::string &t, uint64_t limit, uint64_t &out) {
+	size_t i = (!t.empty() && t[0] == '+') ? 1 : 0;
+	if (i >= t.size()) return false;
+	uint64_t v = 0;
+	for (; i < t.size(); i++) {
+		if (t[i] < '0' || t[i] > '9') return false;
+		if (v > (limit - (uint64_t)(t[i] - '0')) / 10) return false;
+		v = v * 10 + (uint64_t)(t[i] - '0');
+	}
+	out = v;
+	return true;
+}
+struct PlyVertex {
+	V3 position, normal; /* Vertex.uv / .tangent (vertex.rs:8-9, mesh.rs:87-88,:101-108) are never read on the radiance path */
+};
+/* Mesh::load_ply, mesh.rs:58-121.  false where the reference panics (an unwrap() on a missing token / failed parse, an
+ * index past `values` or `vertices`). */
+bool load_ply_text(const std::string &buffer, std::vector<Triangle> &faces) {
+	/* str::lines(): split at '\n', a trailing "\r" is dropped, no empty last line after a final newline */
+	std::vector<std::string> lines;
+	for (size_t i = 0; i < buffer.size();) {
+		size_t j = buffer.find('\n', i);
+		std::string l = buffer.substr(i, (j == std::string::npos ? buffer.size() : j) - i);
+		if (!l.empty() && l.back() == '\r') l.pop_back();
+		lines.push_back(l);
+		if (j == std::string::npos) break;
+		i = j + 1;
+	}
+	size_t li = 0;
+	uint64_t capacity = 0; /* vertices.capacity() after the reserve_exact calls of :72 (len is 0 there) */
+	/* :67-78 header: only `element vertex N` is read */
+	while (li < lines.size()) {
+		std::vector<std::string> tok = split_ws(lines[li++]);
+		if (tok.empty()) return false; /* tokens.next().unwrap() */
+		if (tok[0] == "element") {
+			if (tok.size() < 2) return false;
+			if (tok[1] == "vertex") {
+				uint64_t n;
+				if (tok.size() < 3 || !parse_uint(tok[2], UINT64_MAX, n)) return false;
+				capacity = std::max(capacity, n);
+			}
+		} else if (tok[0] == "end_header") {
+			break;
+		}
+	}
+	/* :81-91 vertices: x y z nx ny nz [s t] */
+	std::vector<PlyVertex> vertices;
+	for (uint64_t k = 0; k < capacity; k++) {
+		if (li >= lines.size()) return false; /* lines.next().unwrap() */
+		std::vector<std::string> tok = split_ws(lines[li++]);
+		std::vector<double> values;
+		for (const std::string &t : tok) {
+			double v;
+			if (!parse_f64(t, v)) return false;
+			values.push_back(v);
+		}
+		if (values.size() < 6) return false; /* values[5] */
+		vertices.push_back(PlyVertex{v3(values[0], values[1], values[2]), v3(values[3], values[4], values[5])});
+	}
+	/* :94-118 faces: `3 i j k`; lines with another first value are skipped */
+	faces.clear();
+	while (li < lines.size()) {
+		std::vector<std::string> tok = split_ws(lines[li++]);
+		std::vector<uint64_t> values;
+		for (const std::string &t : tok) {
+			uint64_t v;
+			if (!parse_uint(t, 0xFFFFFFFFull, v)) return false;
+			values.push_back(v);
+		}
+		if (values.empty()) return false; /* values[0] */
+		if (values[0] == 3) {
+			if (values.size() < 4) return false;
+			for (int k = 1; k <= 3; k++)
+				if (values[k] >= vertices.size()) return false;
+			const PlyVertex &a = vertices[values[1]], &b = vertices[values[2]], &c = vertices[values[3]];
+			faces.push_back(Triangle{a.position, b.position, c.position, a.normal, b.normal, c.normal});
+		}
+	}
+	return true;
+}
+/* Mesh::bake_transform, mesh.rs:48-56 */
+void bake_transform(std::vector<Triangle> &tris, V3 translate) {
+	for (Triangle &t : tris) t.p0 = t.p0 + translate, t.p1 = t.p1 + translate, t.p2 = t.p2 + translate;
+}
+
 } // namespace
 
 struct orc_grid {
 	AccGrid g;
+};
+struct orc_mesh {
+	std::vector<Triangle> triangles;
+	std::vector<double> pos, nrm;
+	void refresh() {
+		pos.resize(triangles.size() * 9), nrm.resize(triangles.size() * 9);
+		for (size_t i = 0; i < triangles.size(); i++) {
+			const Triangle &t = triangles[i];
+			v3_store(&pos[9 * i], t.p0), v3_store(&pos[9 * i + 3], t.p1), v3_store(&pos[9 * i + 6], t.p2);
+			v3_store(&nrm[9 * i], t.n0), v3_store(&nrm[9 * i + 3], t.n1), v3_store(&nrm[9 * i + 6], t.n2);
+		}
+	}
 };
 struct orc_scene {
 	Scene scene;
@@ -906,6 +1032,55 @@ void orc_render_tiles(const orc_scene *s, const rmd_camera *cam, const rmd_setti
 	std::vector<std::thread> pool;
 	for (uint32_t i = 0; i < n_threads; i++) pool.emplace_back(worker);
 	for (auto &t : pool) t.join();
+}
+
+/* Mesh::load_ply (mesh.rs:58-121) from the text of a file */
+int32_t orc_mesh_load_ply_text(const char *text, size_t n_bytes, orc_mesh **out) {
+	auto m = std::make_unique<orc_mesh>();
+	if (!load_ply_text(std::string(text, n_bytes), m->triangles)) return 1;
+	m->refresh();
+	*out = m.release();
+	return 0;
+}
+int32_t orc_mesh_load_ply(const char *path, orc_mesh **out) {
+	FILE *f = std::fopen(path, "rb");
+	if (!f) return 1; /* fs::read_to_string(path).unwrap() */
+	std::string buf;
+	char chunk[65536];
+	size_t n;
+	while ((n = std::fread(chunk, 1, sizeof(chunk), f)) > 0) buf.append(chunk, n);
+	std::fclose(f);
+	return orc_mesh_load_ply_text(buf.data(), buf.size(), out);
+}
+void orc_mesh_bake_transform(orc_mesh *m, const double translate[3]) {
+	bake_transform(m->triangles, v3_from(translate));
+	m->refresh();
+}
+uint64_t orc_mesh_size(const orc_mesh *m) { return m->triangles.size(); }
+void orc_mesh_arrays(const orc_mesh *m, const double **tri_pos, const double **tri_nrm) { *tri_pos = m->pos.data(), *tri_nrm = m->nrm.data(); }
+/* Mesh::find_mesh_bounds, mesh.rs:123-140 (Q9 seed constants) */
+void orc_mesh_bounds(const orc_mesh *m, double bbox_min[3], double bbox_max[3]) {
+	AABB b = mesh_bounds(m->triangles);
+	v3_store(bbox_min, b.min), v3_store(bbox_max, b.max);
+}
+void orc_mesh_destroy(orc_mesh *m) { delete m; }
+
+/* TaskHandle::await's division (src/trace.rs:95) followed by cli_old/src/main.rs:161-181:
+ *   tone_mapped = 1 - exp(p * -1.0 * exposure);  tone_mapped = tone_mapped.powf(1.0 / gamma);
+ *   (tone_mapped * 255.0).cast::<u8>()  -> None (pixel stays (0,0,0), :176-181) if any channel is NaN or outside (-1, 256) */
+void orc_resolve_tonemap(const double *accum, size_t n_pixels, double sample_count, double exposure, double gamma, uint8_t *rgb8) {
+	for (size_t i = 0; i < n_pixels; i++) {
+		double v[3];
+		bool ok = true;
+		for (int c = 0; c < 3; c++) {
+			double p = accum[i * 3 + c] / sample_count;
+			double tm = 1.0 - std::exp(p * -1.0 * exposure);
+			tm = std::pow(tm, 1.0 / gamma);
+			v[c] = tm * 255.0;
+			ok = ok && (v[c] > -1.0 && v[c] < 256.0);
+		}
+		for (int c = 0; c < 3; c++) rgb8[i * 3 + c] = ok ? (uint8_t)v[c] : (uint8_t)0;
+	}
 }
 
 void orc_walk_hist(uint64_t out[4 * 65 + 1]) {

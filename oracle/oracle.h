@@ -57,6 +57,20 @@ int32_t orc_grid_build(const double *tri_pos, const double *tri_nrm, uint64_t n_
 void orc_grid_describe(const orc_grid *g, rmd_grid_desc *desc);
 void orc_grid_destroy(orc_grid *g);
 
+/* Mesh (core/src/geometry/mesh.rs): ASCII-PLY loader :58-121, bake_transform :48-56, find_mesh_bounds :123-140.
+ * load returns 0, or 1 where the reference panics (missing file, malformed line, vertex index out of range). */
+typedef struct orc_mesh orc_mesh;
+int32_t orc_mesh_load_ply(const char *path, orc_mesh **out);
+int32_t orc_mesh_load_ply_text(const char *text, size_t n_bytes, orc_mesh **out);
+void orc_mesh_bake_transform(orc_mesh *m, const double translate[3]);
+uint64_t orc_mesh_size(const orc_mesh *m);
+void orc_mesh_arrays(const orc_mesh *m, const double **tri_pos, const double **tri_nrm); /* n*9 doubles each, owned by m */
+void orc_mesh_bounds(const orc_mesh *m, double bbox_min[3], double bbox_max[3]);
+void orc_mesh_destroy(orc_mesh *m);
+
+/* Output stage: await's division by the sample count (src/trace.rs:95), then tone-map / gamma / u8 cast (cli_old/src/main.rs:161-181) */
+void orc_resolve_tonemap(const double *accum, size_t n_pixels, double sample_count, double exposure, double gamma, uint8_t *rgb8);
+
 /* scene */
 orc_scene *orc_scene_create(const rmd_object *objects, uint32_t n_objects, const rmd_grid_desc *grids,
                             uint32_t n_grids);

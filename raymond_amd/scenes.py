@@ -114,6 +114,19 @@ def gold_dragon_standin(n=91, grid_builder=None):
     return scene
 
 
+def mesh_scene(mesh, translate=(0.0, -0.3, 2.9), grid_builder=None):
+    """cli_old/src/main.rs:45-127 with `mesh` (e.g. one of the reference's assets/meshes/*.ply, loaded by Mesh.load_ply) in
+    the dragon's place: load (:60), bake_transform (:61), build_from_mesh (:63), gold Metal material (:72-75)."""
+    mesh = Mesh(mesh.tri_pos.copy(), mesh.tri_nrm.copy())
+    mesh.bake_transform(translate)
+    grid = (grid_builder or AccGrid.build_from_mesh)(mesh)
+    scene = Scene()
+    scene.objects.append(Object(Sphere((-1.0, -0.5, 3.5), 0.5), Material.Diffuse((1.0, 0.0, 0.0), 0.02)))
+    scene.objects.append(Object(Grid(grid), Material.Metal((1.0, 1.0, 0.1), 0.15)))
+    scene.objects.extend(_room_planes())
+    return scene
+
+
 def camera(width, height, aperture_radius=0.0):
     """cli_old/src/main.rs:134-141 at the requested resolution."""
     return CameraSettings(width, height, 55.0, Transform.identity(), focal_length=2.5, aperture_radius=aperture_radius)

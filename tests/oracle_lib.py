@@ -44,6 +44,14 @@ _SIGS = {
     "orc_trace_sample": (C.c_int32, [_vp, _P(abi.Camera), _P(abi.Settings), C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "orc_trace_samples": (None, [_vp, _P(abi.Camera), _P(abi.Settings), _sz, _vp, _vp, _vp]),
     "orc_render_tiles": (None, [_vp, _P(abi.Camera), _P(abi.Settings), _P(abi.TileRect), C.c_uint32, _vp, C.c_uint32]),
+    "orc_mesh_load_ply": (C.c_int32, [C.c_char_p, _P(_vp)]),
+    "orc_mesh_load_ply_text": (C.c_int32, [C.c_char_p, _sz, _P(_vp)]),
+    "orc_mesh_bake_transform": (None, [_vp, _vp]),
+    "orc_mesh_size": (C.c_uint64, [_vp]),
+    "orc_mesh_arrays": (None, [_vp, _P(_vp), _P(_vp)]),
+    "orc_mesh_bounds": (None, [_vp, _vp, _vp]),
+    "orc_mesh_destroy": (None, [_vp]),
+    "orc_resolve_tonemap": (None, [_vp, _sz, C.c_double, C.c_double, C.c_double, _vp]),
     "orc_counters_reset": (None, []),
     "orc_counters_get": (None, [_vp]),
 }
@@ -153,6 +161,47 @@ def grid_build(mesh):
     g = AccGrid.from_desc(d)
     lib.orc_grid_destroy(h)
     return 0, g
+
+
+def load_ply(path=None, text=None, translate=None):
+    """Oracle's Mesh::load_ply (+ optional bake_transform) -> (rc, raymond_amd.scene.Mesh or None, (bbox_min, bbox_max)).
+    rc = 1 where the reference would panic."""
+    from raymond_amd.scene import Mesh
+
+    lib = load()
+    h = C.c_void_p()
+    if text is not None:
+        raw = text if isinstance(text, bytes) else text.encode()
+        rc = lib.orc_mesh_load_ply_text(raw, len(raw), C.byref(h))
+    else:
+        rc = lib.orc_mesh_load_ply(str(path).encode(), C.byref(h))
+    if rc != 0:
+        return rc, None, None
+    try:
+        if translate is not None:
+            t = f64(translate)
+            lib.orc_mesh_bake_transform(h, ptr(t))
+        n = int(lib.orc_mesh_size(h))
+        pp, pn = C.c_void_p(), C.c_void_p()
+        lib.orc_mesh_arrays(h, C.byref(pp), C.byref(pn))
+        if n:
+            pos = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_double)), shape=(n * 9,)).copy()
+            nrm = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_double)), shape=(n * 9,)).copy()
+        else:
+            pos = nrm = np.zeros(0)
+        mn, mx = np.zeros(3), np.zeros(3)
+        lib.orc_mesh_bounds(h, ptr(mn), ptr(mx))
+        return 0, Mesh(pos.reshape(-1, 9), nrm.reshape(-1, 9)), (mn, mx)
+    finally:
+        lib.orc_mesh_destroy(h)
+
+
+def resolve_tonemap(accum, sample_count, exposure=1.0, gamma=2.2):
+    """await's division + cli_old's tone-map / gamma / u8 cast -> uint8 array of accum's shape."""
+    a = f64(accum)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    load().orc_resolve_tonemap(ptr(a), a.size // 3, float(sample_count), float(exposure), float(gamma), ptr(out))
+    return out
 
 
 def counters():

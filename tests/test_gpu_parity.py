@@ -371,8 +371,9 @@ def test_config1_image(gpu_ctx, oracle):
     assert abs(dev.mean() - ref.mean()) <= 1e-3 * ref.mean()
     # tone-mapped 8-bit output (cli_old/src/main.rs:161-181) is identical wherever the radiance agrees
     rgb8 = render.resolve_tonemap(gpu_ctx, fb, st.sample_count)
-    ref8 = np.trunc(255.0 * np.power(1.0 - np.exp(-(ref / 16.0)), 1.0 / 2.2)).astype(np.uint8)
-    assert (rgb8[ok] == ref8[ok]).mean() >= 0.999
+    ref8 = oracle.resolve_tonemap(ref, 16)  # the oracle's restatement of await's division + cli_old/src/main.rs:161-181
+    assert (rgb8[ok] == ref8[ok]).mean() >= 0.999  # exp/pow differ by an ulp between libm and the device: a truncation may flip
+    assert np.abs(rgb8[ok].astype(int) - ref8[ok].astype(int)).max() <= 1
     fb.close()
     ds.close()
 

@@ -1,0 +1,310 @@
+"""The HIP path held directly against what the reference itself holds — its one render of this scene
+(examples/ReflectiveSpheres.png, README.md:24: 592x340, 500 spp, 5 bounces) and its own mesh assets
+(assets/meshes/*.ply, parsed into tests/golden/ref_mesh_*.npz by tools/gen_ref_fixtures.py) — and tile-mode launches
+(`rmd_render_tiles`, the production instantiations `render_kernel<tiles | tiles-buffered, grid>` + `sum_kernel`) against
+the oracle's `render_tiles` on mesh scenes, thin lens included, up to a 3840x2160 launch.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from raymond_amd import abi, probe, render, scenes
+from raymond_amd.scene import AccGrid, Mesh, Settings, generate_tiles
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+with open(os.path.join(GOLD, "ref_meshes.json")) as _f:
+    FIX = json.load(_f)
+BAKE = tuple(FIX["bake_translation"])
+
+
+def rel_close(a, b, rtol):
+    return (np.abs(a - b) <= rtol * np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-300)) | (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def fixture_mesh(name):
+    z = np.load(os.path.join(GOLD, "ref_mesh_%s.npz" % name))
+    return Mesh(z["tri_pos"], z["tri_nrm"])
+
+
+def gpu_frame(ctx, scene, st, begin=0, count=None):
+    cam = st.camera_settings
+    W, H = cam.backbuffer_width, cam.backbuffer_height
+    ds = render.DeviceScene(ctx, scene)
+    fb = render.Framebuffer(ctx, W, H)
+    render.render_tiles(ctx, ds, cam, st, generate_tiles(W, H, st.tile_size), fb, begin, count)
+    img = fb.download()
+    rgb8 = render.resolve_tonemap(ctx, fb, st.sample_count if count is None else count)
+    fb.close(), ds.close()
+    return img, rgb8
+
+
+# ------------------------------------------------------------------ the reference's own render
+def blocks_of(rgb8):
+    return rgb8[:336].astype(np.float64).reshape(42, 8, 74, 8, 3).mean(axis=(1, 3))
+
+
+def test_gpu_render_matches_the_reference_png_at_its_own_500_spp(gpu_ctx):
+    """ReflectiveSpheres exactly as README.md:24 states it — 592x340, 500 spp, 5 bounces, cli_old's tone-map — rendered by
+    the HIP path and compared, as 8x8 block means of the 8-bit image, with the reference's examples/ReflectiveSpheres.png
+    (tests/golden/png_blocks.npy).  The two renders use different random numbers, so the yardstick is Monte-Carlo noise
+    itself: a second HIP render with another seed.  |HIP - PNG| must be distributed like |HIP(seed A) - HIP(seed B)|:
+    measured (oracle, same configuration): mean 0.435 vs 0.456 of 255, 99th percentile 2.20 vs 2.17, signed mean
+    +0.004 per channel.  A wrong exponent, clamp, pdf constant or material anywhere in the integrator shifts whole
+    regions by many times that."""
+    ref = np.load(os.path.join(GOLD, "png_blocks.npy")).astype(np.float64)
+    sc = scenes.reflective_spheres()
+    frames = []
+    for seed in (scenes.SEED, scenes.SEED + 17):
+        st = Settings(scenes.camera(592, 340), sample_count=500, tile_size=(32, 32), bounce_limit=5, seed=seed)
+        frames.append(blocks_of(gpu_frame(gpu_ctx, sc, st)[1]))
+    a, b = frames
+    d_self, d_ref = np.abs(a - b), np.abs(a - ref)
+    assert 0.2 < d_self.mean() < 0.8  # the noise floor itself is where the oracle puts it (0.456)
+    assert d_ref.mean() <= 1.15 * d_self.mean(), (d_ref.mean(), d_self.mean())
+    assert np.percentile(d_ref, 99) <= 1.25 * np.percentile(d_self, 99) + 0.25
+    assert d_ref.max() <= 1.5 * d_self.max() + 1.0
+    # no bias: the signed mean over the 3,108 blocks is within 5 sigma of 0 (sigma from the seed-to-seed differences)
+    sigma = (a - b).std() / np.sqrt(2.0)
+    assert np.abs((a - ref).mean(axis=(0, 1))).max() <= 5.0 * sigma * np.sqrt(2.0) / np.sqrt(a.shape[0] * a.shape[1]) + 0.02
+    # ... and region by region (block coordinates; the spheres project to (202, 216) r 47 and (365, 193) r 70 pixels)
+    yy, xx = np.mgrid[0:42, 0:74]
+    regions = {
+        "red diffuse sphere": (xx * 8 + 4 - 202.2) ** 2 + (yy * 8 + 4 - 216.2) ** 2 < 38.0**2,
+        "blue metal sphere with its reflections": (xx * 8 + 4 - 364.5) ** 2 + (yy * 8 + 4 - 192.8) ** 2 < 60.0**2,
+        "floor": (yy >= 36),
+        "back wall above the spheres": (yy >= 10) & (yy < 14) & (xx > 20) & (xx < 55),
+    }
+    for name, m in regions.items():
+        n = int(m.sum())
+        assert n >= 20, name
+        bias = (a[m] - ref[m]).mean(axis=0)
+        noise = (a[m] - b[m]).std() / np.sqrt(n)  # std of a region mean of seed-to-seed differences
+        assert np.abs(bias).max() <= 5.0 * noise + 0.05, (name, bias, noise)
+        assert np.abs(a[m] - ref[m]).mean() <= 1.3 * np.abs(a[m] - b[m]).mean() + 0.05, name
+    # the ceiling is the emitter: 1.5 radiance -> trunc(255 * (1 - e^-1.5)^(1/2.2)) = 227 in the PNG and here, exactly
+    assert (ref[0, 18:56] == 227.0).all() and (a[0, 18:56] == 227.0).all() and (b[1, 19:55] == 227.0).all()
+
+
+# ------------------------------------------------------------------ the reference's own meshes
+@pytest.mark.parametrize("name", sorted(FIX["meshes"]))
+def test_gpu_grid_builder_on_the_reference_assets(gpu_ctx, name):
+    """rmd_grid_build_from_mesh_gpu on the reference's meshes (baked as cli_old does): the fixture's tables bit for bit,
+    or RMD_ERR_GRID_INDEX where the reference's index arithmetic panics (suzanne.ply)."""
+    from raymond_amd import lib
+
+    fx = FIX["meshes"][name]["grid_baked"]
+    mesh = fixture_mesh(name)
+    mesh.bake_transform(BAKE)
+    assert sha(mesh.tri_pos) == FIX["meshes"][name]["baked_tri_pos_sha256"]
+    if "panics" in fx:
+        with pytest.raises(lib.RaymondError) as e:
+            AccGrid.build_from_mesh(mesh, ctx=gpu_ctx)
+        assert e.value.status == abi.RMD_ERR_GRID_INDEX
+        return
+    g = AccGrid.build_from_mesh(mesh, ctx=gpu_ctx)
+    assert [int(v) for v in g.resolution] == fx["resolution"]
+    assert [float(v).hex() for v in g.bbox_min] == fx["bounds_min"] and [float(v).hex() for v in g.cell_size] == fx["cell_size"]
+    assert sha(g.cells) == fx["cells_sha256"] and sha(g.mapping_table) == fx["mapping_sha256"]
+
+
+@pytest.mark.parametrize("name", ["suzanne_flat", "monkeysmooth", "ico_sphere", "cube"])
+def test_per_sample_parity_on_the_reference_meshes(gpu_ctx, oracle, name):
+    """cli_old's scene with one of the reference's meshes in the dragon's place: 6,000 (pixel, sample) pairs, hit sequence
+    (object and triangle per depth) bit-exact, radiance within 1e-9 relative."""
+    sc = scenes.mesh_scene(fixture_mesh(name), BAKE)
+    st = Settings(scenes.camera(480, 270), sample_count=1, bounce_limit=5, seed=scenes.SEED + 3)
+    cam = st.camera_settings
+    rng = np.random.default_rng(7)
+    n = 6000
+    xy = np.stack([rng.integers(100, 380, n), rng.integers(40, 250, n)], axis=1).astype(np.uint32)
+    smp = rng.integers(0, 500, n).astype(np.uint32)
+    ds, osc = render.DeviceScene(gpu_ctx, sc), oracle.OracleScene(sc)
+    drgb, dpo, dps = probe.trace_samples(gpu_ctx, ds, cam, st, xy, smp, paths=True)
+    ds.close()
+    same = np.zeros(n, dtype=bool)
+    orgb = np.zeros((n, 3))
+    for i in range(n):
+        rgb, po, ps = osc.trace_sample_path(cam, st, int(xy[i, 0]), int(xy[i, 1]), int(smp[i]))
+        orgb[i] = rgb
+        k = len(po)
+        same[i] = (dpo[i, :k] == po).all() and (dps[i, :k] == ps).all() and (dpo[i, k:] == -2).all()
+    assert same.mean() >= 0.999, same.mean()
+    assert rel_close(drgb[same], orgb[same], 1e-9).all()
+    assert (dpo == 1).any(axis=1).mean() > (0.3 if name in ("suzanne_flat", "monkeysmooth") else 0.03)  # the mesh is on these paths
+
+
+# ------------------------------------------------------------------ tile mode (the production kernels) against the oracle
+def compare_frames(dev, ref, spp, min_exact=0.995):
+    """Tile-mode frames: every pixel within 1e-9 relative of the oracle's sequential sum, except pixels in which an
+    ulp-level difference in sin/cos flipped a whole sample (counted, bounded)."""
+    ok = rel_close(dev, ref, 1e-9).all(axis=2)
+    assert ok.mean() >= min_exact, "pixels off: %d of %d" % ((~ok).sum(), ok.size)
+    assert np.abs(dev - ref)[~ok].max(initial=0.0) <= spp * 1.5 * 8  # a flipped sample changes a pixel by at most a sample's radiance
+    assert abs(dev.mean() - ref.mean()) <= 2e-3 * ref.mean()
+    return ok
+
+
+@pytest.mark.parametrize("case", ["lumpy", "suzanne_flat", "lumpy-thin-lens", "suzanne_flat-direct"])
+def test_tile_mode_mesh_frames_against_the_oracle(gpu_ctx, oracle, case):
+    """`rmd_render_tiles` on grid scenes — pool + walk batching + per-sample buffer + sum_kernel (automatic split), and the
+    one-wave-per-tile instantiation (split forced to 1) — against `oracle.render_tiles` (src/trace.rs:197-205 run tile by
+    tile), 160x96, 4 spp; the thin-lens case through generate_primary_ray_with_dof.  Then the 8-bit output stage against
+    the oracle's restatement of cli_old/src/main.rs:161-181."""
+    if case.startswith("lumpy"):
+        sc = scenes.gold_dragon_standin(n=12)
+    else:
+        sc = scenes.mesh_scene(fixture_mesh("suzanne_flat"), BAKE)
+    dof = case.endswith("thin-lens")
+    st = Settings(scenes.camera(160, 96, aperture_radius=0.5 if dof else 0.0), sample_count=4, bounce_limit=5, seed=scenes.SEED + 9, use_dof=dof)
+    cam = st.camera_settings
+    tiles = generate_tiles(160, 96, st.tile_size)
+    gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 1 if case.endswith("direct") else 0)
+    try:
+        dev, rgb8 = gpu_frame(gpu_ctx, sc, st)
+    finally:
+        gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0)
+    ref = oracle.OracleScene(sc).render_tiles(cam, st, tiles)
+    ok = compare_frames(dev, ref, 4)
+    ref8 = oracle.resolve_tonemap(ref, 4)
+    assert (rgb8[ok] == ref8[ok]).mean() >= 0.999  # exp/pow differ by an ulp between libm and the device: a truncation may flip
+    assert np.abs(rgb8[ok].astype(int) - ref8[ok].astype(int)).max() <= 1
+    if dof:
+        # the aperture really is in use: the pinhole frame of the same settings differs
+        pin = Settings(cam, sample_count=4, bounce_limit=5, seed=scenes.SEED + 9, use_dof=False)
+        assert not np.array_equal(gpu_frame(gpu_ctx, sc, pin)[0], dev)
+
+
+def test_aperture_radius_alone_does_not_switch_the_thin_lens_on(gpu_ctx, oracle):
+    """The reference's loop always calls the pinhole generator (src/trace.rs:199) whatever CameraSettings.aperture_radius
+    holds (server/src/main.rs:149 sets 0.5): without RMD_RENDER_DOF the frame equals the aperture-0 frame bit for bit."""
+    sc = scenes.reflective_spheres()
+    frames = []
+    for ap in (0.0, 0.5):
+        st = Settings(scenes.camera(96, 64, aperture_radius=ap), sample_count=3, bounce_limit=4, seed=5)
+        frames.append(gpu_frame(gpu_ctx, sc, st)[0])
+    assert frames[0].tobytes() == frames[1].tobytes()
+    st = Settings(scenes.camera(96, 64, aperture_radius=0.5), sample_count=3, bounce_limit=4, seed=5)
+    ref = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, generate_tiles(96, 64, (32, 32)))
+    compare_frames(frames[1], ref, 3)
+
+
+@pytest.fixture(scope="module")
+def dragon(product_lib):
+    return scenes.gold_dragon_standin()
+
+
+def test_c4_shaped_launch(gpu_ctx, oracle, dragon):
+    """3840x2160, 8 bounces on the 99,372-triangle stand-in (BASELINE.json configs[3]) through `rmd_render_tiles`, 16 spp:
+    (a) 400 spot pixels — all 16 samples each — equal the oracle's sequential sums; (b) a scratch cap that forces the
+    launch into two 8-sample passes (api.cpp multi-pass path) gives the same frame bit for bit; (c) 5 + 11 samples in two
+    calls likewise; (d) finite, non-negative, ceiling strip = 16 x emission."""
+    st = scenes.config_settings("C4", spp=16)
+    cam = st.camera_settings
+    W, H = cam.backbuffer_width, cam.backbuffer_height
+    assert (W, H, st.bounce_limit) == (3840, 2160, 8)
+    tiles = generate_tiles(W, H, st.tile_size)
+    ds = render.DeviceScene(gpu_ctx, dragon)
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+    full = fb.download()
+    assert np.isfinite(full).all() and (full >= 0).all()
+    assert (full[2, W // 4 : 3 * W // 4] == 16 * 1.5).all()  # 16 samples x emission 1.5, seen directly
+    # (a)
+    rng = np.random.default_rng(11)
+    n = 400
+    px = np.stack([rng.integers(int(0.25 * W), int(0.75 * W), n), rng.integers(int(0.25 * H), int(0.9 * H), n)], axis=1)
+    px[: n // 4] = np.stack([rng.integers(0, W, n // 4), rng.integers(0, H, n // 4)], axis=1)
+    xy = np.repeat(px, 16, axis=0).astype(np.uint32)
+    smp = np.tile(np.arange(16, dtype=np.uint32), n)
+    o = oracle.OracleScene(dragon).trace_samples(cam, st, xy, smp).reshape(n, 16, 3)
+    acc = np.zeros((n, 3))
+    for s in range(16):
+        acc = acc + o[:, s]  # src/trace.rs:203, in sample order
+    got = full[px[:, 1], px[:, 0]]
+    ok = rel_close(got, acc, 1e-9).all(axis=1)
+    assert ok.mean() >= 0.99, ok.mean()
+    # (b) two passes of 8 samples: the cap is sized so that 16 samples do not fit and 8 do
+    bytes_per_sample = (W // 8) * (H // 8) * 64 * 24
+    gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, (bytes_per_sample * 12) >> 20)
+    try:
+        fb.zero()
+        render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+        assert fb.download().tobytes() == full.tobytes()
+    finally:
+        gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, 0)
+    # (c)
+    fb.zero()
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, 0, 5)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, 5, 11)
+    assert fb.download().tobytes() == full.tobytes()
+    fb.close(), ds.close()
+
+
+# ------------------------------------------------------------------ one process, several contexts (multi-GPU hosts without MPI)
+def test_two_contexts_render_disjoint_shards_concurrently(gpu_ctx, dragon):
+    """The N-GPU path of a single-process host: one rmd_context per GPU, rmd_render_tiles_async on
+    each, then rmd_context_synchronize.  Rehearsed here with two contexts on the one GPU of the box: their shards, summed,
+    are the full frame bit for bit, and render_tiled() over devices (0, 0) equals devices (0,)."""
+    st = scenes.config_settings("C3", spp=4)
+    cam = st.camera_settings
+    W, H = cam.backbuffer_width, cam.backbuffer_height
+    tiles = generate_tiles(W, H, st.tile_size)
+    ds = render.DeviceScene(gpu_ctx, dragon)
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+    full = fb.download()
+    fb.close(), ds.close()
+    workers = []
+    for k in range(2):
+        c = render.Context(0)
+        workers.append((c, render.DeviceScene(c, dragon), render.Framebuffer(c, W, H)))
+    for k, (c, d, f) in enumerate(workers):
+        render.render_tiles(c, d, cam, st, tiles[k::2], f, sync=False)  # both in flight before either is waited for
+    total = np.zeros_like(full)
+    for c, d, f in workers:
+        c.synchronize()
+        part = f.download()
+        assert ((part != 0) & (total != 0)).sum() == 0
+        total += part
+        f.close(), d.close(), c.close()
+    assert total.tobytes() == full.tobytes()
+    small = Settings(scenes.camera(200, 120), sample_count=6, bounce_limit=5, seed=3, samples_per_iteration=2)
+    sc = scenes.reflective_spheres()
+    one = render.render_tiled(sc, small, devices=(0,)).await_()
+    two = render.render_tiled(sc, small, devices=(0, 0)).await_()
+    assert one.tobytes() == two.tobytes()
+
+
+# ------------------------------------------------------------------ the shipped library ignores RMD_DEBUG
+def test_shipped_library_ignores_rmd_debug():
+    """RMD_DEBUG=1|2 used to skip triangle tests / grid walks in every build; now only `make DIAG=1` builds read it."""
+    code = (
+        "import hashlib, sys; sys.path.insert(0, %r)\n"
+        "from raymond_amd import render, scenes\n"
+        "from raymond_amd.scene import Settings, generate_tiles\n"
+        "st = Settings(scenes.camera(96, 64), sample_count=2, bounce_limit=5, seed=11)\n"
+        "with render.Context(0) as ctx:\n"
+        "    ds = render.DeviceScene(ctx, scenes.gold_dragon_standin(n=8)); fb = render.Framebuffer(ctx, 96, 64)\n"
+        "    render.render_tiles(ctx, ds, st.camera_settings, st, generate_tiles(96, 64, (32, 32)), fb)\n"
+        "    print(hashlib.sha256(fb.download().tobytes()).hexdigest())\n" % ROOT
+    )
+    digests = set()
+    for dbg in (None, "1", "2", "3"):
+        env = dict(os.environ)
+        env.pop("RMD_DEBUG", None)
+        if dbg:
+            env["RMD_DEBUG"] = dbg
+        out = subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout.split()
+        digests.add(out[-1])
+    assert len(digests) == 1

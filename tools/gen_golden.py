@@ -176,12 +176,15 @@ def grid_digests():
         json.dump(out, f, indent=1)
 
 
-def work_counters():
-    out = {}
-    for name, spp in (("C1", 16), ("C2", 2), ("C3", 2), ("C5", 2)):
+def work_counters(only=()):
+    path = os.path.join(GOLD, "work_counters.json")
+    out = json.load(open(path)) if only and os.path.exists(path) else {}
+    for name, spp in (("C1", 16), ("C2", 2), ("C3", 2), ("C4", 1), ("C5", 2)):
+        if only and name not in only:
+            continue
         st = scenes.config_settings(name, spp=spp)
         cam = st.camera_settings
-        sc = getattr(scenes, scenes.CONFIGS[name][0])(grid_builder=lambda m: O.grid_build(m)[1]) if name in ("C3", "C5") else scenes.reflective_spheres()
+        sc = getattr(scenes, scenes.CONFIGS[name][0])(grid_builder=lambda m: O.grid_build(m)[1]) if name in ("C3", "C4", "C5") else scenes.reflective_spheres()
         O.counters_reset()
         O.OracleScene(sc).render_tiles(cam, st, generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size))
         c = O.counters()
@@ -265,5 +268,5 @@ if __name__ == "__main__":
     if "png" in which:
         png_blocks()
     if "counters" in which:
-        work_counters()
+        work_counters([w for w in which if w in scenes.CONFIGS])  # e.g. `gen_golden.py counters C4` recounts C4 only
     print("golden fixtures written to", GOLD)

@@ -1,19 +1,72 @@
 #!/usr/bin/env python3
-"""Sums rocprofv3 --pmc counter CSVs per counter for the render kernel:  pmc_summary.py DIR [DIR...]
-Prints counter totals per dispatch (averaged over the render_kernel dispatches of each pass)."""
-import csv, glob, os, sys, collections
+"""Sums rocprofv3 --pmc counter CSVs per counter for the render kernel:  pmc_summary.py [--json OUT.json --tag NAME] DIR [DIR...]
+Prints counter totals per dispatch (averaged over the render_kernel dispatches of each pass).  Directory names are
+<WORKLOAD>_<spp>_<sq|fetch|write> (tools/profile_round.sh).  With --json, also writes what bench.py reads:
+  profiles/pmc_latest.json   per workload: VALU issue occupancy, lane utilisation, wave instructions per sample
+  profiles/hbm_traffic.json  per workload: L2<->fabric bytes per launch = 2 x FETCH_SIZE KiB (gfx950 reports half the bytes of
+                             16-B/lane loads, MI355X_MICROARCH.md) + WRITE_SIZE KiB, render kernel + sum kernel
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
 
-for d in sys.argv[1:]:
+args = sys.argv[1:]
+json_out = tag = None
+while args and args[0].startswith("--"):
+    if args[0] == "--json":
+        json_out = args[1]
+    elif args[0] == "--tag":
+        tag = args[1]
+    args = args[2:]
+
+SAMPLES = {"C2": 1920 * 1080, "C3": 1920 * 1080, "C5": 1920 * 1080, "C4": 3840 * 2160}
+N_SIMD = 256 * 4
+agg = collections.defaultdict(dict)  # (workload, spp) -> counter -> avg per dispatch
+for d in args:
+    base = os.path.basename(d.rstrip("/"))
+    parts = base.split("_")
+    key = (parts[0], int(parts[1])) if len(parts) >= 3 and parts[1].isdigit() else (parts[0], None)
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
             if "render_kernel" in kn:
-                tag = ""
+                t = ""
             elif "sum_kernel" in kn:
-                tag = "[sum_kernel]"
+                t = "[sum_kernel]"
             else:
                 continue
-            per[r["Counter_Name"] + tag].append(float(r["Counter_Value"]))
+            per[r["Counter_Name"] + t].append(float(r["Counter_Value"]))
         for k, v in per.items():
-            print("%-28s %-24s n=%d avg/dispatch=%.6g" % (os.path.basename(d), k, len(v), sum(v) / len(v)))
+            print("%-28s %-24s n=%d avg/dispatch=%.6g" % (base, k, len(v), sum(v) / len(v)))
+            agg[key][k] = sum(v) / len(v)
+
+if json_out:
+    valu, traffic = {}, {"_how": __doc__.split("With --json")[1].strip()}
+    for (wl, spp), c in agg.items():
+        if "SQ_INSTS_VALU" in c and spp:
+            n = SAMPLES[wl] * spp
+            valu[wl] = {
+                "source": tag, "spp": spp,
+                "wave_instr_valu_per_sample": c["SQ_INSTS_VALU"] / n,
+                "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0),
+                # fraction of a wave's resident cycles in which it has a VALU instruction in flight, times the waves per SIMD
+                # resident on average = how busy the SIMD's vector ALU is (1.0 = an instruction issued whenever one could be)
+                "valu_active_per_wave": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                "waves_per_simd": c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"] / 4.0 if c.get("SQ_BUSY_CYCLES") else None,
+                "valu_issue_frac": (c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]) * (c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"] / 4.0) if c.get("SQ_BUSY_CYCLES") else None,
+            }
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            fetch = c["FETCH_SIZE"] + c.get("FETCH_SIZE[sum_kernel]", 0.0)
+            write = c["WRITE_SIZE"] + c.get("WRITE_SIZE[sum_kernel]", 0.0)
+            traffic[wl] = {"source": tag, "spp": spp, "bytes_per_launch": 2.0 * fetch * 1024.0 + write * 1024.0,
+                           "render_fetch_kib": c["FETCH_SIZE"], "render_write_kib": c["WRITE_SIZE"],
+                           "sum_fetch_kib": c.get("FETCH_SIZE[sum_kernel]", 0.0), "sum_write_kib": c.get("WRITE_SIZE[sum_kernel]", 0.0)}
+    os.makedirs(json_out, exist_ok=True)
+    with open(os.path.join(json_out, "pmc_latest.json"), "w") as f:
+        json.dump(valu, f, indent=1)
+    with open(os.path.join(json_out, "hbm_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
