@@ -98,6 +98,20 @@ def load_traffic(name, spp):
     return entry["bytes_per_launch"]
 
 
+def valu_block(name, avg_ms):
+    """The SQ-counter figures of the committed profile plus, from THIS run's launch duration, the time one SIMD spends per
+    vector instruction: 1,024 SIMDs x duration / wave instructions.  A wave64 FP64/INT32 vector instruction occupies its SIMD for
+    4 cycles (1.67 ns at the 2.4 GHz peak clock; ~1.9 ns at the ~2.1 GHz the part sustains under this load), so a value near
+    that means the vector ALUs issue back to back — the launch is VALU-issue bound."""
+    v = load_valu(name)
+    if not v:
+        return None
+    v = dict(v)
+    v["simd_ns_per_valu_instr"] = round(avg_ms * 1e6 * 1024.0 / v["wave_instr_valu_per_launch"], 3)
+    v["valu_issue_floor_ns"] = {"at_2.4GHz": 1.667, "note": "4 cycles per wave64 instruction"}
+    return v
+
+
 def load_valu(name):
     """What bounds a VALU-bound launch, from the committed SQ counter pass (profiles/pmc_latest.json, written by
     tools/pmc_summary.py --json): issue-slot occupancy of the vector ALU, lane utilisation, wave instructions per sample."""
@@ -255,7 +269,7 @@ def main():
         if name == "C2":
             # the real bound of this workload: FP64 vector-ALU issue (the 8-object scene lives in LDS/SGPRs, HBM sees the framebuffer only)
             rl["note"] = "VALU-issue bound, not HBM bound: see `valu`"
-            v = load_valu("C2")
+            v = valu_block("C2", avg_ms) if spp == 500 else None
             if v:
                 rl["valu"] = v
         out["roofline_%s" % name.lower()] = rl
@@ -284,7 +298,7 @@ def main():
             # L2<->fabric bytes per launch by PMC (upper bound on HBM bytes: Infinity-Cache hits are included)
             out["roofline"]["measured_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 3)
             out["roofline"]["measured_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        v = load_valu("C3")
+        v = valu_block("C3", avg_ms) if rspp == 500 else None
         if v:
             out["roofline"]["valu"] = v
     elif rank == 0:

@@ -53,11 +53,10 @@ if json_out:
                 "source": tag, "spp": spp,
                 "wave_instr_valu_per_sample": c["SQ_INSTS_VALU"] / n,
                 "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0),
-                # fraction of a wave's resident cycles in which it has a VALU instruction in flight, times the waves per SIMD
-                # resident on average = how busy the SIMD's vector ALU is (1.0 = an instruction issued whenever one could be)
+                # fraction of a wave's resident cycles in which it has a VALU instruction in flight; times the waves resident per
+                # SIMD (4 for both render kernels) = how busy the SIMD's vector ALU is
                 "valu_active_per_wave": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
-                "waves_per_simd": c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"] / 4.0 if c.get("SQ_BUSY_CYCLES") else None,
-                "valu_issue_frac": (c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]) * (c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"] / 4.0) if c.get("SQ_BUSY_CYCLES") else None,
+                "wave_instr_valu_per_launch": c["SQ_INSTS_VALU"],
             }
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             fetch = c["FETCH_SIZE"] + c.get("FETCH_SIZE[sum_kernel]", 0.0)
