@@ -139,13 +139,19 @@ typedef struct rmd_tile_rect {
 
 /*
  * RNG (replaces rand::random::<f64>() at src/trace.rs:260,287,288,326,327,340,341,397,398).
- * Counter-based Philox4x32-10 (Salmon et al., SC'11), key = (seed lo32, seed hi32),
- * counter = (pixel = y*W + x, sample index, draw_index >> 1, 0).  The block's
- * four words w0..w3 give two uniforms:  draw_index even -> (w1:w0), odd -> (w3:w2),
- * u = (((uint64)hi << 32 | lo) >> 11) * 2^-53  in [0,1).  draw_index counts the
- * calls the reference makes, in its order, within one sample: 0,1 = pixel jitter
- * x,y (:326-327); DoF rejection draws follow (:340-341); then per shaded depth
- * r (:260), r1, r2 (:397-398 or :287-288).
+ * Counter-based Philox4x32-10 (Salmon et al., SC'11), key = (seed lo32, seed hi32).  A sample's random numbers come
+ * in BLOCKS: block b of sample s of pixel p is the Philox output for counter (p = y*W + x, s, b, 0), four words w0..w3:
+ *     u_first  = (((uint64)w1 << 32 | w0) >> 11) * 2^-53        53-bit uniforms in [0,1), as rand 0.6 makes an f64
+ *     u_second = (((uint64)w3 << 32 | w2) >> 11) * 2^-53
+ *     u_22     = ((w0 & 0x7FF) << 11 | (w2 & 0x7FF)) * 2^-22     the 22 bits those two conversions discard
+ * Every consumer takes exactly one block, in the order the reference makes its calls within a sample:
+ *     block 0               pixel jitter: x <- u_first, y <- u_second (:326-327)
+ *     then, thin lens only  one block per round of the rejection loop: r1 <- u_first, r2 <- u_second (:340-341)
+ *     then                  one block per shaded depth: r1 <- u_first, r2 <- u_second (:397-398 or :287-288) and
+ *                           r <- u_22 (:260).  r only decides diffuse against specular: it is compared with prob_d, which
+ *                           is 0.5 for Diffuse and 0.0 for Metal (:263-264), and for those two values a 22-bit uniform
+ *                           gives exactly the probabilities a 53-bit one does.
+ * (One Philox evaluation per path segment, and no RNG state beyond a block counter.)
  */
 
 typedef struct rmd_context rmd_context;

@@ -20,8 +20,10 @@ extern "C" {
 
 /* RNG (replaces rand::random::<f64>(), src/trace.rs:260 etc.) */
 rmd_status rmd_probe_philox4x32_10(rmd_context *ctx, size_t n, const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4);
-rmd_status rmd_probe_uniform(rmd_context *ctx, uint64_t seed, size_t n, const uint32_t *pixel, const uint32_t *sample,
-                             const uint32_t *draw_index, double *out);
+/* per entry 5 doubles: the two 53-bit uniforms and the 22-bit uniform of Philox block `block` of (pixel, sample) as the jitter /
+ * lens draws take them (next2), then (r, r1, r2) as a shaded depth takes them (next3) — include/raymond_hip.h "RNG" */
+rmd_status rmd_probe_block_uniforms(rmd_context *ctx, uint64_t seed, size_t n, const uint32_t *pixel, const uint32_t *sample,
+                                    const uint32_t *block, double *out5);
 /* core/src/geometry/primitives/sphere.rs:11-27, :31-35 */
 rmd_status rmd_probe_sphere_intersect(rmd_context *ctx, size_t n, const double *sphere4, const double *ray6, int32_t *hit, double *t);
 rmd_status rmd_probe_sphere_normal(rmd_context *ctx, size_t n, const double *sphere4, const double *ray6, const double *t, double *n3);

@@ -104,23 +104,37 @@ void philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t 
 	out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
+/* A sample's random numbers come in blocks — one Philox evaluation, counter (pixel, sample, block, 0) — and every consumer
+ * takes one block: block 0 the pixel jitter (:326-327), each round of the lens rejection loop one block (:340-341), each shaded
+ * depth one block (:260 and :397-398 / :287-288).  include/raymond_hip.h "RNG". */
 struct Rng {
 	uint32_t key[2];
 	uint32_t pixel, sample;
-	uint32_t draw = 0;
+	uint32_t block = 0;
 	Rng(uint64_t seed, uint32_t pixel_, uint32_t sample_) : pixel(pixel_), sample(sample_) {
 		key[0] = (uint32_t)seed;
 		key[1] = (uint32_t)(seed >> 32);
 	}
-	static double at(const uint32_t key[2], uint32_t pixel, uint32_t sample, uint32_t draw) {
-		uint32_t ctr[4] = {pixel, sample, draw >> 1, 0u}, w[4];
-		philox4x32_10(ctr, key, w);
-		uint64_t bits = (draw & 1u) ? (((uint64_t)w[3] << 32) | w[2]) : (((uint64_t)w[1] << 32) | w[0]);
-		return (double)(bits >> 11) * (1.0 / 9007199254740992.0); /* 2^-53, [0,1) like rand 0.6 */
+	static double u53(uint32_t lo, uint32_t hi) {
+		return (double)(((((uint64_t)hi) << 32) | lo) >> 11) * (1.0 / 9007199254740992.0); /* 2^-53, [0,1) like rand 0.6 */
 	}
-	double next() {
-		tl_counters.c[K_DRAWS]++;
-		return at(key, pixel, sample, draw++);
+	/* the block's two 53-bit uniforms and the 22-bit uniform made of the bits their conversion discards */
+	static void at(const uint32_t key[2], uint32_t pixel, uint32_t sample, uint32_t block, double &u0, double &u1, double &u22) {
+		uint32_t ctr[4] = {pixel, sample, block, 0u}, w[4];
+		philox4x32_10(ctr, key, w);
+		u0 = u53(w[0], w[1]), u1 = u53(w[2], w[3]);
+		u22 = (double)(((w[0] & 0x7FFu) << 11) | (w[2] & 0x7FFu)) * (1.0 / 4194304.0);
+	}
+	void next2(double &u0, double &u1) { /* two rand::random::<f64>() calls */
+		double unused;
+		tl_counters.c[K_DRAWS] += 2;
+		at(key, pixel, sample, block++, u0, u1, unused);
+	}
+	/* the three calls of one shaded depth, in the reference's order r, r1, r2.  r is only ever compared with prob_d = 0.5
+	 * (Diffuse) or 0.0 (Metal) (:263-264): the 22-bit uniform gives those comparisons the probabilities a 53-bit one does */
+	void next3(double &r, double &r1, double &r2) {
+		tl_counters.c[K_DRAWS] += 3;
+		at(key, pixel, sample, block++, r1, r2, r);
 	}
 };
 
@@ -554,8 +568,8 @@ Ray generate_primary_ray_u(uint32_t xi, uint32_t yi, const rmd_camera &cam, doub
 	return Ray{pos, normalize(v3(px, py, 1.0))};
 }
 Ray generate_primary_ray(uint32_t x, uint32_t y, const rmd_camera &cam, Rng &rng) {
-	double u0 = rng.next(); /* :326 */
-	double u1 = rng.next(); /* :327 */
+	double u0, u1; /* :326, :327 */
+	rng.next2(u0, u1);
 	return generate_primary_ray_u(x, y, cam, u0, u1);
 }
 /* :335-360 (Q12).  `ok` false where the reference's unwrap() would panic. */
@@ -565,8 +579,9 @@ Ray generate_primary_ray_with_dof(uint32_t x, uint32_t y, const rmd_camera &cam,
 	V3 start = pos;
 	/* unbounded in the reference; 4096 rounds (acceptance pi/4 each) is never reached */
 	for (int guard = 0; guard < 4096; guard++) {
-		double r1 = rng.next() * 2.0 - 1.0;
-		double r2 = rng.next() * 2.0 - 1.0;
+		double r1, r2; /* :340-341 */
+		rng.next2(r1, r2);
+		r1 = r1 * 2.0 - 1.0, r2 = r2 * 2.0 - 1.0;
 		double ax = pos.x + r1 * cam.aperture_radius;
 		double ay = pos.y + r2 * cam.aperture_radius;
 		start = v3(ax, ay, pos.z);
@@ -613,13 +628,13 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 	V3 cam_pos = v3(ctx.cam->position[0], ctx.cam->position[1], ctx.cam->position[2]);
 	V3 view_dir = normalize(cam_pos - fragment_position); /* :256 (Q1) */
 	V3 f0 = lerp_vec(v3(0.04, 0.04, 0.04), material_color, material_metalness); /* :257-258 */
-	double r = rng.next(); /* :260 */
+	double r, r1, r2; /* :260, then :397-398 (diffuse) or :287-288 (specular): the depth's three draws come from one block */
+	rng.next3(r, r1, r2);
 	V3 lc_t, lc_b;
 	create_coordinate_system_of_n(normal, lc_t, lc_b); /* :261-262: Matrix3::from_cols(t, normal, b) */
 	double prob_d = lerp(0.5, 0.0, material_metalness); /* :263 */
 	if (r < prob_d) {
 		/* :265-282 diffuse */
-		double r1 = rng.next(), r2 = rng.next();
 		V3 sample;
 		double pdf;
 		uniform_sample_hemisphere(r1, r2, sample, pdf);
@@ -636,7 +651,6 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 	} else {
 		/* :283-319 specular */
 		V3 reflect = normalize(-view_dir - 2.0 * (-dot(view_dir, normal) * normal));
-		double r1 = rng.next(), r2 = rng.next(); /* :287-288 */
 		V3 sample_world = importance_sample_ggx(reflect, material_roughness, r1, r2);
 		V3 radiance = trace(Ray{fragment_position + normal * 0.0001, sample_world}, ctx, rng, depth + 1);
 		double cos_theta = dot(normal, sample_world);
@@ -818,9 +832,9 @@ struct orc_scene {
 extern "C" {
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
-double orc_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw_index) {
+void orc_block_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t block, double out[3]) {
 	uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-	return Rng::at(key, pixel, sample, draw_index);
+	Rng::at(key, pixel, sample, block, out[0], out[1], out[2]);
 }
 
 void orc_sphere_intersect(size_t n, const double *sphere4, const double *ray6, int32_t *hit, double *t) {

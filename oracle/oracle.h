@@ -29,7 +29,8 @@ typedef struct orc_scene orc_scene;
 
 /* RNG */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-double orc_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw_index);
+/* out = { first 53-bit uniform, second 53-bit uniform, 22-bit uniform } of Philox block `block` of (pixel, sample): include/raymond_hip.h "RNG" */
+void orc_block_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t block, double out[3]);
 
 /* Batched device-function KATs.  Rays are 6 doubles (origin xyz, direction xyz).
  * hit[i] = 1/0; t[i] valid when hit. */

@@ -113,51 +113,33 @@ RMD_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 	o0 = c0, o1 = c1, o2 = c2, o3 = c3;
 }
 
-// Per-lane counter RNG: one cached Philox block serves two consecutive draws.
+// Per-lane counter RNG (include/raymond_hip.h "RNG").  A sample's random numbers come in BLOCKS — one Philox4x32-10
+// evaluation, counter (pixel, sample, block, 0) — and every consumer takes exactly one block: block 0 is the pixel jitter,
+// each round of the thin lens' rejection loop one block, each shaded depth one block.  The state is the next block's index.
 struct Rng {
-	uint32_t k0, k1, pixel, sample, draw, blk;
-	uint32_t w0, w1, w2, w3;
-	RMD_DEV void init(uint32_t key0, uint32_t key1, uint32_t pixel_, uint32_t sample_) {
-		k0 = key0, k1 = key1, pixel = pixel_, sample = sample_, draw = 0, blk = 0xFFFFFFFFu;
-		w0 = w1 = w2 = w3 = 0;
-	}
-	RMD_DEV double next() {
-		uint32_t b = draw >> 1;
-		if (b != blk) {
-			philox4x32_10(pixel, sample, b, 0u, k0, k1, w0, w1, w2, w3);
-			blk = b;
-		}
-		uint32_t lo = (draw & 1u) ? w2 : w0, hi = (draw & 1u) ? w3 : w1;
-		draw++;
-		return to_unit(lo, hi);
-	}
-	static RMD_DEV double to_unit(uint32_t lo, uint32_t hi) {
+	uint32_t pixel, sample, block;
+	RMD_DEV void init(uint32_t pixel_, uint32_t sample_) { pixel = pixel_, sample = sample_, block = 0u; }
+	static RMD_DEV double to_unit(uint32_t lo, uint32_t hi) { // 53-bit uniform in [0, 1), as rand 0.6's f64
 		uint64_t bits = (((uint64_t)hi << 32) | lo) >> 11;
 		return (double)bits * (1.0 / 9007199254740992.0);
 	}
-	// The three draws of one shaded depth (r, r1, r2 = draws d, d+1, d+2; src/trace.rs:260 and :397-398 / :287-288) in one
-	// go.  Block (d+2)>>1 is needed by every lane — its first half is r2 for even d, its two halves are r1 and r2 for
-	// odd d — so it is evaluated unconditionally; block d>>1 only by the even-d lanes (odd-d lanes still hold its
-	// second half from the previous depth).  Lanes of a wave sit at both parities, so three separate next() calls would
-	// each run a Philox for part of the wave; this runs two.  Same values as three next() calls.
-	RMD_DEV void next3(double &r, double &r1, double &r2) {
-		const uint32_t d = draw, b1 = (d + 2u) >> 1;
-		uint32_t v0, v1, v2, v3;
-		philox4x32_10(pixel, sample, b1, 0u, k0, k1, v0, v1, v2, v3);
-		if (d & 1u) {
-			if (blk != (d >> 1)) philox4x32_10(pixel, sample, d >> 1, 0u, k0, k1, w0, w1, w2, w3); // never after jitter/DoF/next3
-			r = to_unit(w2, w3);
-			r1 = to_unit(v0, v1);
-			r2 = to_unit(v2, v3);
-		} else {
-			uint32_t u0, u1, u2, u3;
-			philox4x32_10(pixel, sample, d >> 1, 0u, k0, k1, u0, u1, u2, u3);
-			r = to_unit(u0, u1);
-			r1 = to_unit(u2, u3);
-			r2 = to_unit(v0, v1);
-		}
-		w0 = v0, w1 = v1, w2 = v2, w3 = v3, blk = b1;
-		draw = d + 3u;
+	// the 22 bits the two 53-bit conversions of a block discard, as a uniform in [0, 1)
+	static RMD_DEV double to_unit22(uint32_t w0, uint32_t w2) { return (double)(((w0 & 0x7FFu) << 11) | (w2 & 0x7FFu)) * (1.0 / 4194304.0); }
+	// two uniforms: pixel jitter x, y (src/trace.rs:326-327); one round of the lens rejection loop (:340-341)
+	RMD_DEV void next2(uint32_t k0, uint32_t k1, double &u0, double &u1) {
+		uint32_t w0, w1, w2, w3;
+		philox4x32_10(pixel, sample, block, 0u, k0, k1, w0, w1, w2, w3);
+		block++;
+		u0 = to_unit(w0, w1), u1 = to_unit(w2, w3);
+	}
+	// the three draws of one shaded depth: r (:260) decides diffuse against specular — it is only ever compared with 0.5
+	// (Diffuse) or 0.0 (Metal) (:263-264), for which a 22-bit uniform gives the same probabilities as a 53-bit one — and r1, r2
+	// (:397-398 or :287-288) are the block's two 53-bit uniforms
+	RMD_DEV void next3(uint32_t k0, uint32_t k1, double &r, double &r1, double &r2) {
+		uint32_t w0, w1, w2, w3;
+		philox4x32_10(pixel, sample, block, 0u, k0, k1, w0, w1, w2, w3);
+		block++;
+		r = to_unit22(w0, w2), r1 = to_unit(w0, w1), r2 = to_unit(w2, w3);
 	}
 };
 
@@ -410,12 +392,12 @@ struct Bounce {
 	bool specular;
 	V3 next_origin, next_dir;
 };
-RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double metal, V3 cam_pos, Rng &rng) {
+RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double metal, V3 cam_pos, Rng &rng, uint32_t k0, uint32_t k1) {
 	Bounce out;
 	const V3 view = normalize(cam_pos - frag); // :256
 	const V3 f0 = mk(lerp(0.04, color.x, metal), lerp(0.04, color.y, metal), lerp(0.04, color.z, metal)); // :257-258
 	double r, r1, r2; // :260, then :397-398 or :287-288
-	rng.next3(r, r1, r2);
+	rng.next3(k0, k1, r, r1, r2);
 	const double prob_d = lerp(0.5, 0.0, metal); // :263
 	const bool diffuse = r < prob_d;             // :264
 	double phi, pdf_d = 0.0, st, ct, sp, cp;
@@ -494,7 +476,8 @@ RMD_DEV void primary_ray(const RenderParams &P, uint32_t xi, uint32_t yi, double
 }
 // :335-360.  Returns false where the reference's unwrap() on the focal-plane hit would panic.
 RMD_DEV bool primary_ray_dof(const RenderParams &P, uint32_t xi, uint32_t yi, Rng &rng, V3 &ro, V3 &rd) {
-	double u0 = rng.next(), u1 = rng.next();
+	double u0, u1;
+	rng.next2(P.key0, P.key1, u0, u1);
 	V3 po, pd;
 	primary_ray(P, xi, yi, u0, u1, po, pd);
 	V3 pos = ld3(P.cam_pos);
@@ -502,8 +485,9 @@ RMD_DEV bool primary_ray_dof(const RenderParams &P, uint32_t xi, uint32_t yi, Rn
 	// unbounded rejection loop in the reference; 4096 rounds at acceptance pi/4 is never reached,
 	// and gives every wave a guaranteed exit.
 	for (int guard = 0; guard < 4096; guard++) {
-		double r1 = rng.next() * 2.0 - 1.0;
-		double r2 = rng.next() * 2.0 - 1.0;
+		double r1, r2;
+		rng.next2(P.key0, P.key1, r1, r2);
+		r1 = r1 * 2.0 - 1.0, r2 = r2 * 2.0 - 1.0;
 		start = mk(pos.x + r1 * P.aperture_radius, pos.y + r2 * P.aperture_radius, pos.z);
 		if (dist(start, pos) < P.aperture_radius) break;
 	}

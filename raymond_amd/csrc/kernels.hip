@@ -219,7 +219,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 
 	const V3 cam_pos = ld3(P.cam_pos);
 	Rng rng;
-	rng.init(P.key0, P.key1, 0u, 0u);
+	rng.init(0u, 0u);
 	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
 	uint32_t depth = 1; // depth argument of the trace() call being evaluated
 	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
@@ -259,12 +259,13 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 				x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 				s = P.sample_begin + pool_first + (item >> 6);
 			}
-			rng.init(P.key0, P.key1, y * P.W + x, s);
+			rng.init(y * P.W + x, s);
 			bool ok = true;
 			if (P.use_dof) {
 				ok = primary_ray_dof(P, x, y, rng, ro, rd);
 			} else {
-				double u0 = rng.next(), u1 = rng.next();
+				double u0, u1;
+				rng.next2(P.key0, P.key1, u0, u1);
 				primary_ray(P, x, y, u0, u1, ro, rd);
 			}
 			depth = 1;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 #if RMD_DIAG
 					if ((P.debug_flags & 8u) && P.debug_counters) { const unsigned long long sm = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(sm)) atomicAdd(&P.debug_counters[13], (unsigned long long)__popcll(sm)), atomicAdd(&P.debug_counters[14], 1ull); }
 #endif
-					Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
+					Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, P.key0, P.key1);
 					const V3 wgt = bounce_weight(b); // same factors as :281-282 / :315-318, multiplied forward
 					T = hadamard(T, wgt);
 					ro = b.next_origin, rd = b.next_dir;
@@ -418,10 +419,13 @@ __global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const dou
 		o[0] = w0, o[1] = w1, o[2] = w2, o[3] = w3;
 	} break;
 	case PROBE_UNIFORM: {
+		// a = key0, key1, pixel, sample, block: the block's two 53-bit uniforms, its 22-bit uniform, and the same through next3()
 		Rng r;
-		r.init((uint32_t)a[0], (uint32_t)a[1], (uint32_t)a[2], (uint32_t)a[3]);
-		r.draw = (uint32_t)a[4];
-		o[0] = r.next();
+		r.init((uint32_t)a[2], (uint32_t)a[3]);
+		r.block = (uint32_t)a[4];
+		r.next2((uint32_t)a[0], (uint32_t)a[1], o[0], o[1]);
+		r.block = (uint32_t)a[4];
+		r.next3((uint32_t)a[0], (uint32_t)a[1], o[2], o[3], o[4]);
 	} break;
 	case PROBE_SPHERE_INTERSECT: {
 		double t = 0.0;

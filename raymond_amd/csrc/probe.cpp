@@ -95,14 +95,14 @@ rmd_status rmd_probe_philox4x32_10(rmd_context *ctx, size_t n, const uint32_t *c
 	return RMD_OK;
 }
 
-rmd_status rmd_probe_uniform(rmd_context *ctx, uint64_t seed, size_t n, const uint32_t *pixel, const uint32_t *sample,
-                             const uint32_t *draw_index, double *out_u) {
-	if (!pixel || !sample || !draw_index || !out_u) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "probe: null array");
+rmd_status rmd_probe_block_uniforms(rmd_context *ctx, uint64_t seed, size_t n, const uint32_t *pixel, const uint32_t *sample,
+                                    const uint32_t *block, double *out5) {
+	if (!pixel || !sample || !block || !out5) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "probe: null array");
 	std::vector<double> k0(n, (double)(uint32_t)seed), k1(n, (double)(uint32_t)(seed >> 32));
-	std::vector<double> p = widen(pixel, n), s = widen(sample, n), d = widen(draw_index, n), out;
-	if (rmd_status st = run_probe(ctx, rmd::PROBE_UNIFORM, n, {{k0.data(), 1}, {k1.data(), 1}, {p.data(), 1}, {s.data(), 1}, {d.data(), 1}}, 1, out))
+	std::vector<double> p = widen(pixel, n), s = widen(sample, n), d = widen(block, n), out;
+	if (rmd_status st = run_probe(ctx, rmd::PROBE_UNIFORM, n, {{k0.data(), 1}, {k1.data(), 1}, {p.data(), 1}, {s.data(), 1}, {d.data(), 1}}, 5, out))
 		return st;
-	std::memcpy(out_u, out.data(), n * sizeof(double));
+	std::memcpy(out5, out.data(), n * 5 * sizeof(double));
 	return RMD_OK;
 }
 

@@ -2,7 +2,7 @@
 //
 // The megakernel (kernels.hip) ties a lane to a pixel: when a few lanes of a wave need a grid walk the whole wave
 // steps until the longest of those walks ends (~5 of 64 lanes active).  Here a path's state lives in HBM
-// (~130 bytes per pixel; MI355X has 288 GB) and each path segment is evaluated in two dense stages:
+// (~110 bytes per pixel; MI355X has 288 GB) and each path segment is evaluated in two dense stages:
 //
 //   wf_step   one thread per path.  Finishes the previous segment with the hit recorded for it — miss / emission /
 //             depth cut-off: pixel += T (.) L, next sample's primary ray; otherwise shade, T <- T (.) w, bounce ray —
@@ -35,8 +35,7 @@ struct WfState {
 	int32_t *hit_obj; // [S] closest object so far, -1 none
 	uint32_t *hit_sub;
 	uint32_t *sample; // [S] current sample index
-	uint32_t *draw;   // [S] rng draw counter, and its cached Philox block
-	uint32_t *blk, *w0, *w1, *w2, *w3;
+	uint32_t *block;  // [S] rng: index of the sample's next Philox block
 	uint32_t *flags;  // [S] bit 0 alive, bit 1 fresh (needs a primary ray), bits 8.. depth
 	uint32_t *queue;  // [S] slots that need a grid walk this step
 	uint32_t *counters; // [0],[1]: walk queue lengths (alternating per step), [2]: active paths
@@ -85,9 +84,7 @@ __global__ __launch_bounds__(256) void wf_step(RenderParams P, WfState st, const
 	const V3 cam_pos = ld3(P.cam_pos);
 
 	Rng rng;
-	rng.k0 = P.key0, rng.k1 = P.key1, rng.pixel = pixel;
-	rng.sample = st.sample[slot], rng.draw = st.draw[slot], rng.blk = st.blk[slot];
-	rng.w0 = st.w0[slot], rng.w1 = st.w1[slot], rng.w2 = st.w2[slot], rng.w3 = st.w3[slot];
+	rng.pixel = pixel, rng.sample = st.sample[slot], rng.block = st.block[slot];
 	uint32_t s = rng.sample;
 	const uint32_t s_end = P.sample_begin + P.sample_count;
 	uint32_t depth = flags >> 8;
@@ -119,7 +116,7 @@ __global__ __launch_bounds__(256) void wf_step(RenderParams P, WfState st, const
 					const DevGrid &g = grids[o.grid_index];
 					normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, as_global(g.tri_aux) + (size_t)sub * 4, frag);
 				}
-				Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng);
+				Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, P.key0, P.key1);
 				const V3 wgt = bounce_weight(b);
 				T = hadamard(T, wgt);
 				ro = b.next_origin, rd = b.next_dir;
@@ -136,12 +133,13 @@ __global__ __launch_bounds__(256) void wf_step(RenderParams P, WfState st, const
 	}
 	// ---- primary ray(s): a sample that ends before its first intersection (bounce_limit 0, failed DoF) is consumed here
 	while (fresh && s != s_end) {
-		rng.init(P.key0, P.key1, pixel, s);
+		rng.init(pixel, s);
 		bool ok = true;
 		if (P.use_dof) {
 			ok = primary_ray_dof(P, x, y, rng, ro, rd);
 		} else {
-			double u0 = rng.next(), u1 = rng.next();
+			double u0, u1;
+			rng.next2(P.key0, P.key1, u0, u1);
 			primary_ray(P, x, y, u0, u1, ro, rd);
 		}
 		depth = 1;
@@ -178,8 +176,7 @@ __global__ __launch_bounds__(256) void wf_step(RenderParams P, WfState st, const
 	st.ray[0 * (size_t)S + slot] = ro.x, st.ray[1 * (size_t)S + slot] = ro.y, st.ray[2 * (size_t)S + slot] = ro.z;
 	st.ray[3 * (size_t)S + slot] = rd.x, st.ray[4 * (size_t)S + slot] = rd.y, st.ray[5 * (size_t)S + slot] = rd.z;
 	st.thr[0 * (size_t)S + slot] = T.x, st.thr[1 * (size_t)S + slot] = T.y, st.thr[2 * (size_t)S + slot] = T.z;
-	st.sample[slot] = s, st.draw[slot] = rng.draw, st.blk[slot] = rng.blk;
-	st.w0[slot] = rng.w0, st.w1[slot] = rng.w1, st.w2[slot] = rng.w2, st.w3[slot] = rng.w3;
+	st.sample[slot] = s, st.block[slot] = rng.block;
 	st.flags[slot] = kAlive | (depth << 8);
 	if (walk) st.queue[atomicAdd(&st.counters[step_parity], 1u)] = slot;
 }
@@ -228,7 +225,7 @@ __global__ __launch_bounds__(256) void wf_walk(RenderParams P, WfState st, const
 // ---------------------------------------------------------------- host driver
 size_t wavefront_workspace_bytes(uint32_t n_wave_tiles) {
 	const size_t S = (size_t)n_wave_tiles * 64u;
-	return S * (6 + 3 + 1) * sizeof(double) + S * (1 + 1 + 1 + 1 + 4 + 1 + 1 + 1) * sizeof(uint32_t) + 64;
+	return S * (6 + 3 + 1) * sizeof(double) + S * (1 + 1 + 1 + 1 + 1 + 1) * sizeof(uint32_t) + 64;
 }
 
 hipError_t launch_wavefront(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const WaveTile *wave_tiles,
@@ -245,8 +242,7 @@ hipError_t launch_wavefront(hipStream_t stream, const RenderParams &P, const Dev
 	st.ray = (double *)take(S * 6 * sizeof(double));
 	st.thr = (double *)take(S * 3 * sizeof(double));
 	st.hit_t = (double *)take(S * sizeof(double));
-	st.hit_obj = (int32_t *)take(S * 4), st.hit_sub = (uint32_t *)take(S * 4), st.sample = (uint32_t *)take(S * 4), st.draw = (uint32_t *)take(S * 4);
-	st.blk = (uint32_t *)take(S * 4), st.w0 = (uint32_t *)take(S * 4), st.w1 = (uint32_t *)take(S * 4), st.w2 = (uint32_t *)take(S * 4), st.w3 = (uint32_t *)take(S * 4);
+	st.hit_obj = (int32_t *)take(S * 4), st.hit_sub = (uint32_t *)take(S * 4), st.sample = (uint32_t *)take(S * 4), st.block = (uint32_t *)take(S * 4);
 	st.flags = (uint32_t *)take(S * 4), st.queue = (uint32_t *)take(S * 4);
 	st.counters = (uint32_t *)take(64);
 	st.S = (uint32_t)S;

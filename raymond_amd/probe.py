@@ -11,7 +11,7 @@ _sz = C.c_size_t
 _P = C.POINTER
 _SIGS = {
     "rmd_probe_philox4x32_10": [_vp, _sz, _vp, _vp, _vp],
-    "rmd_probe_uniform": [_vp, C.c_uint64, _sz, _vp, _vp, _vp, _vp],
+    "rmd_probe_block_uniforms": [_vp, C.c_uint64, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_sphere_intersect": [_vp, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_sphere_normal": [_vp, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_plane_intersect": [_vp, _sz, _vp, _vp, _vp, _vp],
@@ -84,11 +84,12 @@ def philox(ctx, ctr, key):
     return out
 
 
-def uniform(ctx, seed, pixel, sample, draw):
+def block_uniforms(ctx, seed, pixel, sample, block):
+    """-> (n, 5): u53_0, u53_1 of the block as next2() returns them, then r (22-bit), r1, r2 as next3() returns them"""
     L = _L()
-    pixel, sample, draw = (np.ascontiguousarray(a, dtype=np.uint32) for a in (pixel, sample, draw))
-    out = np.zeros(pixel.shape[0])
-    ctx.check(L.rmd_probe_uniform(ctx.handle, seed, pixel.shape[0], _p(pixel), _p(sample), _p(draw), _p(out)))
+    pixel, sample, block = (np.ascontiguousarray(a, dtype=np.uint32) for a in (pixel, sample, block))
+    out = np.zeros((pixel.shape[0], 5))
+    ctx.check(L.rmd_probe_block_uniforms(ctx.handle, seed, pixel.shape[0], _p(pixel), _p(sample), _p(block), _p(out)))
     return out
 
 

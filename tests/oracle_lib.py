@@ -20,7 +20,7 @@ _vp = C.c_void_p
 _sz = C.c_size_t
 _SIGS = {
     "orc_philox4x32_10": (None, [_vp, _vp, _vp]),
-    "orc_uniform": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "orc_block_uniforms": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "orc_sphere_intersect": (None, [_sz, _vp, _vp, _vp, _vp]),
     "orc_sphere_normal": (None, [_sz, _vp, _vp, _vp, _vp]),
     "orc_plane_intersect": (None, [_sz, _vp, _vp, _vp, _vp]),
@@ -201,6 +201,17 @@ def resolve_tonemap(accum, sample_count, exposure=1.0, gamma=2.2):
     a = f64(accum)
     out = np.zeros(a.shape, dtype=np.uint8)
     load().orc_resolve_tonemap(ptr(a), a.size // 3, float(sample_count), float(exposure), float(gamma), ptr(out))
+    return out
+
+
+def block_uniforms(seed, pixel, sample, block):
+    """-> (n, 3): first and second 53-bit uniform and the 22-bit uniform of each (pixel, sample, block)"""
+    lib = load()
+    out = np.zeros((len(pixel), 3))
+    row = np.zeros(3)
+    for i, (p, s, b) in enumerate(zip(pixel, sample, block)):
+        lib.orc_block_uniforms(seed, int(p), int(s), int(b), ptr(row))
+        out[i] = row
     return out
 
 

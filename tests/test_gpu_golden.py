@@ -42,8 +42,8 @@ def test_function_known_answers(gpu_ctx):
     assert close(D[:, 0], kat["brdf_D"], 1e-15).all() and close(G[:, 0], kat["brdf_G"], 1e-15).all()
     (F,) = probe.call(gpu_ctx, "fresnel_schlick", n, [kat["fresnel_cos"], kat["fresnel_f0"]], [3])
     assert close(F, kat["fresnel_out"], 1e-13).all()
-    u = probe.uniform(gpu_ctx, scenes.SEED, kat["rng_pixel"], kat["rng_sample"], kat["rng_draw"])
-    assert np.array_equal(u, kat["rng_u"])
+    u = probe.block_uniforms(gpu_ctx, scenes.SEED, kat["rng_pixel"], kat["rng_sample"], kat["rng_block"])
+    assert np.array_equal(u[:, :3], kat["rng_u"]) and np.array_equal(u[:, [3, 4, 2]], kat["rng_u"])  # next2 and next3 read the same block
     pr = probe.primary_ray(gpu_ctx, scenes.camera(1920, 1080), kat["pray_xy"], kat["pray_u"])
     assert close(pr, kat["pray_out"], 1e-15).all()
 

@@ -76,12 +76,12 @@ def test_uniform_stream_bit_exact(gpu_ctx, oracle):
     rng = np.random.default_rng(1)
     pixel = rng.integers(0, 1920 * 1080, N, dtype=np.uint32)
     sample = rng.integers(0, 4000, N, dtype=np.uint32)
-    draw = rng.integers(0, 64, N, dtype=np.uint32)
+    block = rng.integers(0, 40, N, dtype=np.uint32)
     seed = 0x5EED0001_0BADF00D
-    dev = probe.uniform(gpu_ctx, seed, pixel, sample, draw)
-    L = oracle.load()
-    ref = np.array([L.orc_uniform(seed, int(p), int(s), int(d)) for p, s, d in zip(pixel, sample, draw)])
-    assert np.array_equal(dev, ref)
+    dev = probe.block_uniforms(gpu_ctx, seed, pixel, sample, block)
+    ref = oracle.block_uniforms(seed, pixel, sample, block)
+    assert np.array_equal(dev[:, :3], ref)                 # next2: first, second (+ the 22-bit uniform of the same block)
+    assert np.array_equal(dev[:, [3, 4, 2]], ref)          # next3: (r, r1, r2) = (22-bit, first, second)
     assert dev.min() >= 0.0 and dev.max() < 1.0
 
 

@@ -45,16 +45,31 @@ def test_philox_random123_known_answers(oracle):
 
 
 def test_uniform_definition(oracle):
-    """u = ((hi << 32 | lo) >> 11) * 2^-53 with (w1:w0) for even draws, (w3:w2) for odd; counter (pixel, sample, draw >> 1, 0)."""
+    """include/raymond_hip.h "RNG": block b of (pixel, sample) = Philox(counter (pixel, sample, b, 0)); its two 53-bit uniforms
+    are ((w1:w0) >> 11) * 2^-53 and ((w3:w2) >> 11) * 2^-53, its 22-bit uniform the bits those shifts discard."""
     L = oracle.load()
     seed, pixel, sample = 0x0123456789ABCDEF, 777, 42
-    for draw in range(6):
-        c = np.array([pixel, sample, draw >> 1, 0], dtype=np.uint32)
+    for block in range(6):
+        c = np.array([pixel, sample, block, 0], dtype=np.uint32)
         k = np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint32)
         w = np.zeros(4, dtype=np.uint32)
         L.orc_philox4x32_10(oracle.ptr(c), oracle.ptr(k), oracle.ptr(w))
-        lo, hi = (int(w[2]), int(w[3])) if draw & 1 else (int(w[0]), int(w[1]))
-        assert L.orc_uniform(seed, pixel, sample, draw) == ((hi << 32 | lo) >> 11) * 2.0**-53
+        w = [int(v) for v in w]
+        u = oracle.block_uniforms(seed, [pixel], [sample], [block])[0]
+        assert u[0] == ((w[1] << 32 | w[0]) >> 11) * 2.0**-53 and u[1] == ((w[3] << 32 | w[2]) >> 11) * 2.0**-53
+        assert u[2] == (((w[0] & 0x7FF) << 11) | (w[2] & 0x7FF)) * 2.0**-22 and 0.0 <= u[2] < 1.0
+
+
+def test_22_bit_uniform_decides_like_a_53_bit_one(oracle):
+    """r (src/trace.rs:260) is compared with prob_d = lerp(0.5, 0.0, metalness) = 0.5 or 0.0 only (:263-264): P(r < 0.5) must be
+    exactly one half — it is the top bit of the 22 — and r < 0.0 never holds; r is independent of r1 and r2 (disjoint bits)."""
+    n = 20000
+    rng = np.random.default_rng(3)
+    u = oracle.block_uniforms(scenes.SEED, rng.integers(0, 2**21, n), rng.integers(0, 500, n), rng.integers(1, 6, n))
+    assert abs((u[:, 2] < 0.5).mean() - 0.5) < 4 * 0.5 / np.sqrt(n) and (u[:, 2] >= 0.0).all()
+    assert np.array_equal(u[:, 2] < 0.5, ((u[:, 2] * 2.0**22).astype(np.int64) >> 21) == 0)
+    for k in (0, 1):
+        assert abs(np.corrcoef(u[:, 2], u[:, k])[0, 1]) < 4 / np.sqrt(n)
 
 
 # ------------------------------------------------------------------ closed-form known answers
@@ -157,7 +172,7 @@ def test_function_fixtures(oracle, kat):
     F = np.zeros((n, 3))
     L.orc_fresnel_schlick(n, P(kat["fresnel_cos"]), P(kat["fresnel_f0"]), P(F))
     assert close(F, kat["fresnel_out"], 1e-13)
-    u = np.array([L.orc_uniform(scenes.SEED, int(p), int(s), int(d_)) for p, s, d_ in zip(kat["rng_pixel"], kat["rng_sample"], kat["rng_draw"])])
+    u = oracle.block_uniforms(scenes.SEED, kat["rng_pixel"], kat["rng_sample"], kat["rng_block"])
     assert np.array_equal(u, kat["rng_u"])
     pr = np.zeros((n, 6))
     cp = scenes.camera(1920, 1080).pod()

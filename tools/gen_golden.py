@@ -119,9 +119,9 @@ def kat_functions():
     # RNG stream + primary rays
     pix = rng.integers(0, 1920 * 1080, N).astype(np.uint32)
     smp = rng.integers(0, 4000, N).astype(np.uint32)
-    drw = rng.integers(0, 64, N).astype(np.uint32)
-    out["rng_pixel"], out["rng_sample"], out["rng_draw"] = pix, smp, drw
-    out["rng_u"] = np.array([L.orc_uniform(scenes.SEED, int(p_), int(s_), int(d_)) for p_, s_, d_ in zip(pix, smp, drw)])
+    blk = rng.integers(0, 32, N).astype(np.uint32)
+    out["rng_pixel"], out["rng_sample"], out["rng_block"] = pix, smp, blk
+    out["rng_u"] = O.block_uniforms(scenes.SEED, pix, smp, blk)
     cam = scenes.camera(1920, 1080)
     xy = np.stack([rng.integers(0, 1920, N), rng.integers(0, 1080, N)], axis=1).astype(np.uint32)
     u = rng.uniform(0, 1, (N, 2))
