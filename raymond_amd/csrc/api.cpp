@@ -427,6 +427,12 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	if (rmd_status s = check_render_args(ctx, scene, camera, settings)) return s;
 	if (!accum_dev || (n_tiles && !tiles)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_render_tiles: null tiles/accum pointer");
 	if (rmd_status s = prepare_wave_tiles(ctx, camera, tiles, n_tiles)) return s;
+	if (settings->bounce_limit == 0u) { // trace(.., 1) with depth 1 > bounce_limit returns (0, 0, 0) unintersected (src/trace.rs:235-237): pixel += 0
+		RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+		RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+		ctx->timed = true;
+		return RMD_OK;
+	}
 	rmd::RenderParams P = rmd::make_params(ctx, scene, camera, settings);
 	P.n_work = ctx->n_wave_tiles;
 	if (P.debug_flags & 24u) {

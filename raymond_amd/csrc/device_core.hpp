@@ -376,97 +376,135 @@ RMD_DEV double pow5(double x) {
 }
 RMD_DEV V3 sel(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
-// One evaluation of the shading half of trace() (src/trace.rs:256-319) for a non-emissive hit.
-// Everything the reference computes after its recursive call depends only on values known before it, so the
-// bounce weight is produced here:
-//   diffuse  (:281-282): out = ((A (.) radiance) * cos) / d1           A = diffuse_part (.) color, d1 = prob_d * pdf
-//   specular (:315-318): out = (((A (.) radiance) * cos) / d1) / d2    A = specular, d1 = 1 - prob_d, d2 = pdf
-// Diffuse and specular lanes of a wave share one instruction stream for everything the two branches have in common —
-// the azimuth's sin/cos, the frame transform, the half vector and the Fresnel term — with
-// per-lane selects choosing the branch's inputs; every lane still performs exactly its own branch's operations in
-// the reference's order.  Only the short branch-specific pieces (the polar angle's sin/cos, the reflection vector, the
-// D/G terms) remain divergent.
-struct Bounce {
-	V3 A;
-	double cosv, d1, d2;
-	bool specular;
-	V3 next_origin, next_dir;
+// The "next ray" of a path, for both ways a path gets one:
+//   SHADE  the shading half of trace() (src/trace.rs:256-319) for a non-emissive hit at a depth below the bounce limit:
+//          the bounce ray, and the bounce's weight multiplied into the throughput T.  Everything the reference computes
+//          after its recursive call depends only on values known before it, so the weight is produced here:
+//            diffuse  (:281-282): out = ((A (.) radiance) * cos) / d1           A = diffuse_part (.) color, d1 = prob_d * pdf
+//            specular (:315-318): out = (((A (.) radiance) * cos) / d1) / d2    A = specular, d1 = 1 - prob_d, d2 = pdf
+//   PRIM   generate_primary_ray (:322-333) for the first segment of a new sample (pinhole; the thin lens has its own routine).
+// A wave's lanes are at different points of their paths, and both kinds need the same two expensive things — one Philox block
+// and one normalisation of the new direction — so the two are ONE instruction stream here, with per-lane selects for the
+// inputs: the Philox evaluation (shade: the depth's block; prim: block 0 of the new sample), its two 53-bit conversions and
+// normalize() run once for every lane of the wave that needs a ray of either kind.  Within SHADE, diffuse and specular lanes
+// likewise share what the two branches have in common — the azimuth's sin/cos, the frame transform, the half vector and the
+// Fresnel term; only the polar angle's sin/cos, the reflection vector and the D/G terms stay divergent.  Every lane still
+// performs exactly its own branch's operations in the reference's order.
+// Must be called in wave-uniform control flow; a lane with neither flag set is left untouched.
+struct NextRayShadeIn {
+	V3 normal, frag, color;
+	double roughness, metal;
 };
-RMD_DEV Bounce shade(V3 normal, V3 frag, V3 color, double roughness, double metal, V3 cam_pos, Rng &rng, uint32_t k0, uint32_t k1) {
-	Bounce out;
-	const V3 view = normalize(cam_pos - frag); // :256
-	const V3 f0 = mk(lerp(0.04, color.x, metal), lerp(0.04, color.y, metal), lerp(0.04, color.z, metal)); // :257-258
-	double r, r1, r2; // :260, then :397-398 or :287-288
-	rng.next3(k0, k1, r, r1, r2);
-	const double prob_d = lerp(0.5, 0.0, metal); // :263
-	const bool diffuse = r < prob_d;             // :264
-	double phi, pdf_d = 0.0, st, ct, sp, cp;
-	V3 axis;
-	if (diffuse) {
-		// uniform_sample_hemisphere (:396-406), frame around the normal (:261-262)
-		const double sr = sqrt64(r1);
-		hemisphere_sincos(sr, st, ct);
-		phi = 2.0 * kPi * r2;
-		pdf_d = sr;
-		axis = normal;
-	} else {
-		// importance_sample_ggx (:286-296), frame around the mirror direction (:285)
-		const double a = roughness * roughness;
-		phi = 2.0 * kPi * r1;
-		sincos_cw(a * sqrt64(r2 / (1.0 - r2)), st, ct);
-		axis = normalize(-view - 2.0 * (-dot(view, normal) * normal));
+RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const NextRayShadeIn &in, V3 cam_pos, uint32_t prim_x, uint32_t prim_y, Rng &rng,
+                      V3 &ro, V3 &rd, V3 &T) {
+	const bool gen = do_shade || do_prim;
+	double u_first = 0.0, u_second = 0.0, r = 0.0;
+	if (gen) {
+		uint32_t w0, w1, w2, w3;
+		philox4x32_10(rng.pixel, rng.sample, rng.block, 0u, P.key0, P.key1, w0, w1, w2, w3);
+		rng.block++;
+		u_first = Rng::to_unit(w0, w1), u_second = Rng::to_unit(w2, w3);
+		r = Rng::to_unit22(w0, w2); // shade only (:260)
 	}
-	sincos_cw(phi, sp, cp);
-	const V3 local = mk(st * cp, ct, st * sp);
-	V3 tg, bt;
-	onb(axis, tg, bt);
-	const V3 sw = normalize(mat3_mul(tg, axis, bt, local)); // :266 / :295
-	out.next_origin = frag + normal * (diffuse ? 0.00001 : 0.0001); // :269 / :300
-	out.next_dir = sw;
-	const double n_dot_sw = dot(normal, sw);
-	// :276 halfway of (sample_world, view); :307-308 halfway of (normalize(sample_world), view)
-	const V3 light = diffuse ? sw : normalize(sw);
-	const V3 halfway = normalize(light + view);
-	const double h_dot_v = dot(halfway, view);
-	const double fc = diffuse ? fmax(h_dot_v, 0.0) : h_dot_v; // :277 clamps, :309 does not
-	const V3 F = f0 + (mk(1.0, 1.0, 1.0) - f0) * pow5(1.0 - fc); // fresnel_schlick :384-386
-	out.specular = !diffuse;
-	if (diffuse) {
-		out.cosv = fmax(n_dot_sw, 0.0);                            // :275
-		const V3 diffuse_part = (mk(1.0, 1.0, 1.0) - F) * (1.0 - metal); // :279-280
-		out.A = hadamard(diffuse_part, color);
-		out.d1 = prob_d * pdf_d;
-		out.d2 = 1.0;
-	} else {
-		const double D = ggx_distribution(normal, halfway, roughness);
-		const double G = geometry_smith(normal, view, sw, roughness);
-		const V3 nominator = (D * G) * F;
-		const double denominator = 4.0 * dot(normal, view) * n_dot_sw + 0.001;
-		out.A = nominator * (1.0 / denominator); // :313 divides each channel; A only scales the weight, see bounce_weight()
-		out.cosv = n_dot_sw; // :306 unclamped
-		out.d1 = 1.0 - prob_d;
-		out.d2 = (D * dot(normal, halfway)) / (4.0 * h_dot_v) + 0.0001; // :317
+	// ---- SHADE, first half: the direction before its normalisation
+	V3 pre = mk(0.0, 0.0, 1.0), view = pre, f0 = pre;
+	bool diffuse = false;
+	double prob_d = 0.0, pdf_d = 0.0;
+	if (do_shade) {
+		const V3 normal = in.normal;
+		view = normalize(cam_pos - in.frag); // :256
+		f0 = mk(lerp(0.04, in.color.x, in.metal), lerp(0.04, in.color.y, in.metal), lerp(0.04, in.color.z, in.metal)); // :257-258
+		const double r1 = u_first, r2 = u_second; // :397-398 or :287-288
+		prob_d = lerp(0.5, 0.0, in.metal);         // :263
+		diffuse = r < prob_d;                      // :264
+		double phi, st, ct, sp, cp;
+		V3 axis;
+		if (diffuse) {
+			// uniform_sample_hemisphere (:396-406), frame around the normal (:261-262)
+			const double sr = sqrt64(r1);
+			hemisphere_sincos(sr, st, ct);
+			phi = 2.0 * kPi * r2;
+			pdf_d = sr;
+			axis = normal;
+		} else {
+			// importance_sample_ggx (:286-296), frame around the mirror direction (:285)
+			const double a = in.roughness * in.roughness;
+			phi = 2.0 * kPi * r1;
+			sincos_cw(a * sqrt64(r2 / (1.0 - r2)), st, ct);
+			axis = normalize(-view - 2.0 * (-dot(view, normal) * normal));
+		}
+		sincos_cw(phi, sp, cp);
+		const V3 local = mk(st * cp, ct, st * sp);
+		V3 tg, bt;
+		onb(axis, tg, bt);
+		pre = mat3_mul(tg, axis, bt, local); // :266 / :295 before normalize()
 	}
-	return out;
+	// ---- PRIM: generate_primary_ray's direction before its normalisation (:326-331)
+	if (do_prim) {
+		const double x = (double)prim_x + (u_first - 0.5);
+		const double y = (double)prim_y + (u_second - 0.5);
+		// (x + 0.5) / width and (y + 0.5) / height (:326-327) through the exact reciprocals when the host provided them
+		const double sx = P.inv_width == P.inv_width ? div_by(x + 0.5, P.width, P.inv_width) : (x + 0.5) / P.width;
+		const double sy = P.inv_height == P.inv_height ? div_by(y + 0.5, P.height, P.inv_height) : (y + 0.5) / P.height;
+		pre = mk((2.0 * sx - 1.0) * P.tan_half_fov * P.aspect, (1.0 - 2.0 * sy) * P.tan_half_fov, 1.0);
+	}
+	V3 sw = pre;
+	if (gen) sw = normalize(pre); // :266 / :295 / :332
+	if (do_prim) {
+		ro = cam_pos, rd = sw;
+		T = mk(1.0, 1.0, 1.0);
+	}
+	// ---- SHADE, second half: the bounce's weight (:275-282 / :301-318) and the bounce ray's origin (:269 / :300)
+	if (do_shade) {
+		const V3 normal = in.normal;
+		const double n_dot_sw = dot(normal, sw);
+		// :276 halfway of (sample_world, view); :307-308 halfway of (normalize(sample_world), view)
+		const V3 light = diffuse ? sw : normalize(sw);
+		const V3 halfway = normalize(light + view);
+		const double h_dot_v = dot(halfway, view);
+		const double fc = diffuse ? fmax(h_dot_v, 0.0) : h_dot_v; // :277 clamps, :309 does not
+		const V3 F = f0 + (mk(1.0, 1.0, 1.0) - f0) * pow5(1.0 - fc); // fresnel_schlick :384-386
+		V3 A;
+		double cosv, d;
+		if (diffuse) {
+			cosv = fmax(n_dot_sw, 0.0);                                        // :275
+			const V3 diffuse_part = (mk(1.0, 1.0, 1.0) - F) * (1.0 - in.metal); // :279-280
+			A = hadamard(diffuse_part, in.color);
+			d = prob_d * pdf_d; // :282
+		} else {
+			const double D = ggx_distribution(normal, halfway, in.roughness);
+			const double G = geometry_smith(normal, view, sw, in.roughness);
+			const V3 nominator = (D * G) * F;
+			const double denominator = 4.0 * dot(normal, view) * n_dot_sw + 0.001;
+			A = nominator * (1.0 / denominator); // :313 divides each channel; A only scales the weight, see below
+			cosv = n_dot_sw;                     // :306 unclamped
+			const double d2 = (D * dot(normal, halfway)) / (4.0 * h_dot_v) + 0.0001; // :317
+			d = (1.0 - prob_d) * d2;                                                 // :318 divides by (1 - prob_d), then by pdf
+		}
+		// Weight of the bounce.  trace() returns  diffuse (:281-282)  ((A (.) radiance) * cos) / (prob_d * pdf)
+		//                                         specular (:315-318) (((A (.) radiance) * cos) / (1 - prob_d)) / pdf
+		// i.e. radiance times a per-channel weight known before the recursive call; the kernel multiplies the weights forward
+		// into the throughput instead of applying them on the way back up.  The weight is formed with ONE
+		// reciprocal — (A * cos) * (1 / d) — instead of three or six correctly rounded divisions: a weight is a product of ~10
+		// rounded factors either way (<= 1 ulp more per bounce, against a 1e-9 bar), it never feeds a direction or a branch, and
+		// f64 division is the most expensive operation on this path (v_rcp_f64 issues at 1/3 rate + 10 FMAs).
+		const V3 wgt = (A * cosv) * (1.0 / d);
+		T = hadamard(T, wgt);
+		ro = in.frag + normal * (diffuse ? 0.00001 : 0.0001); // :269 / :300
+		rd = sw;
+	}
 }
-
-// Weight of one bounce.  trace() returns  diffuse (:281-282)  ((A (.) radiance) * cos) / (prob_d * pdf)
-//                                         specular (:315-318) (((A (.) radiance) * cos) / (1 - prob_d)) / pdf
-// i.e. radiance times a per-channel weight known before the recursive call; the kernel multiplies the weights forward
-// into a throughput instead of applying them on the way back up.  The weight is formed with ONE
-// reciprocal — (A * cos) * (1 / d1[*d2]) — instead of three or six correctly rounded divisions: a weight is a product
-// of ~10 rounded factors either way (<= 1 ulp more per bounce, against a 1e-9 bar), it never feeds a direction or a
-// branch, and f64 division is the most expensive operation on this path (v_rcp_f64 issues at 1/3 rate + 10 FMAs).
-RMD_DEV V3 bounce_weight(const Bounce &b) {
-	const double inv = 1.0 / (b.specular ? b.d1 * b.d2 : b.d1);
-	return (b.A * b.cosv) * inv;
+// The shading half alone (the streaming pipeline's step kernel, and the reading order of the reference): same function.
+RMD_DEV void shade(const RenderParams &P, V3 normal, V3 frag, V3 color, double roughness, double metal, V3 cam_pos, Rng &rng, V3 &ro, V3 &rd, V3 &T) {
+	NextRayShadeIn in{normal, frag, color, roughness, metal};
+	next_ray(P, true, false, in, cam_pos, 0u, 0u, rng, ro, rd, T);
 }
 
 // ---------------------------------------------------------------- ray generation (src/trace.rs:322-360)
+// :322-333 with the two jitter uniforms given (known-answer probe, thin lens); the render loop's pinhole rays come out of next_ray()
 RMD_DEV void primary_ray(const RenderParams &P, uint32_t xi, uint32_t yi, double u0, double u1, V3 &ro, V3 &rd) {
 	double x = (double)xi + (u0 - 0.5);
 	double y = (double)yi + (u1 - 0.5);
-	// (x + 0.5) / width and (y + 0.5) / height (:326-327) through the exact reciprocals when the host provided them
 	const double sx = P.inv_width == P.inv_width ? div_by(x + 0.5, P.width, P.inv_width) : (x + 0.5) / P.width;
 	const double sy = P.inv_height == P.inv_height ? div_by(y + 0.5, P.height, P.inv_height) : (y + 0.5) / P.height;
 	double px = (2.0 * sx - 1.0) * P.tan_half_fov * P.aspect;

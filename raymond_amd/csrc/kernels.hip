@@ -176,7 +176,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	// next item, so no lane sits out while the longest pixel of the tile finishes (which lane computes a sample has no
 	// influence on its value: the RNG is keyed by pixel and sample, and sum_kernel adds the samples in order).
 	uint32_t x = 0, y = 0, s = 0, s_end = 0;
-	bool alive = false;
+	bool alive = false; // the lane has samples left (direct / list) — buffered mode: the lane holds a pool item
 	size_t out_index = 0;
 	uint32_t list_idx = 0;
 	WaveTile tile = {};
@@ -216,6 +216,10 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 
 	V3 acc = mk(0.0, 0.0, 0.0);
 	if (!LIST && alive && !to_buffer) acc = ld3(out + out_index);
+	if (P.bounce_limit == 0u) { // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237): every sample is (0, 0, 0)
+		if (LIST && writes) out[out_index + 0] = 0.0, out[out_index + 1] = 0.0, out[out_index + 2] = 0.0;
+		return; // tile launches with bounce_limit 0 are not made at all (api.cpp): the frame is unchanged
+	}
 
 	const V3 cam_pos = ld3(P.cam_pos);
 	Rng rng;
@@ -224,7 +228,18 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	uint32_t depth = 1; // depth argument of the trace() call being evaluated
 	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
 	uint32_t path_len = 0;
-	bool fresh = true;
+	// Every trip of the loop has two halves.  (B) each lane that needs a ray gets one — the bounce ray of the hit its last
+	// intersection found (`to_shade`), or the primary ray of the next sample when its path has ended (`need_sample`) — in ONE
+	// merged instruction stream (next_ray).  (A) every lane that has a ray intersects it with the scene and classifies the hit.
+	bool need_sample = alive || to_buffer; // no path yet
+	bool has_ray = false, to_shade = false;
+	// the hit a lane will shade on its next trip: object and distance (the hit point and the material are re-derived from them),
+	// and the surface normal — in registers, or, in the grid kernel (which runs at its register limit), parked in the wave's
+	// walk scratch: that LDS is only in use during a walk, i.e. never between the end of (A) and the next (B)
+	int hit_obj = -1;
+	double hit_t = 0.0;
+	V3 hit_normal = mk(0.0, 0.0, 1.0);
+	double *parked_normal = GRID ? reinterpret_cast<double *>(wave_lds) + lane : nullptr; // [0], [64], [128]
 	// grid scenes: a ray's closest plane/sphere hit while the lane waits for the walk that settles the grids (see intersect_simple)
 	bool new_ray = false, waiting = false;
 	uint32_t trips_since_walk = 0; // wave-uniform
@@ -233,56 +248,72 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	uint32_t part_sub = 0;
 
 	// Wave-uniform main loop: all 64 lanes stay in it until every lane has finished its samples, so that finished
-	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated on `alive`.
+	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated.
 	for (;;) {
+		// ---------------- (B) hand out samples, then rays
+		bool prim = false;
 		if constexpr (to_buffer) {
-			// hand the next pool items to the lanes that have none
-			const unsigned long long idle = __ballot(!alive);
+			// the next pool items go to the lanes whose path has ended
+			const unsigned long long idle = __ballot(need_sample);
 			if (idle != 0ull && next_item < pool_items) {
 				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				next_item += (uint32_t)__popcll(idle);
-				if (!alive && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) // slots outside a ragged tile are skipped
-					item = k, alive = true, fresh = true;
+				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) { // slots outside a ragged tile are skipped
+					item = k, prim = true;
+					x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
+					s = P.sample_begin + pool_first + (item >> 6);
+				}
 			}
+			alive = prim || has_ray || to_shade;
 			if (__ballot(alive) == 0ull) {
 				if (next_item >= pool_items) break;
-				continue;
+				continue; // a handout that fell entirely on slots outside the tile
 			}
-		} else if (__ballot(alive) == 0ull) {
-			break;
+		} else {
+			if (need_sample) {
+				if (s != s_end) prim = true; // src/trace.rs:199 — primary ray of sample s
+				else alive = false;
+			}
+			if (__ballot(alive) == 0ull) break;
 		}
-		bool terminal = false;
-		V3 L = mk(0.0, 0.0, 0.0);
-		if (alive && fresh) {
-			// src/trace.rs:199 — primary ray of sample s
-			if constexpr (to_buffer) {
-				x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
-				s = P.sample_begin + pool_first + (item >> 6);
-			}
+		if (prim) {
+			need_sample = false;
 			rng.init(y * P.W + x, s);
-			bool ok = true;
-			if (P.use_dof) {
-				ok = primary_ray_dof(P, x, y, rng, ro, rd);
-			} else {
-				double u0, u1;
-				rng.next2(P.key0, P.key1, u0, u1);
-				primary_ray(P, x, y, u0, u1, ro, rd);
-			}
 			depth = 1;
-			T = mk(1.0, 1.0, 1.0);
-			fresh = false, new_ray = true;
-			if (!ok) terminal = true;                  // reference panics here; the sample contributes zero
-			if (P.bounce_limit == 0u) terminal = true; // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237)
+			has_ray = true, new_ray = true;
 		}
-		const bool want = alive && !terminal;
+		bool lens_failed = false;
+		if (P.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
+			if (prim) {
+				T = mk(1.0, 1.0, 1.0);
+				lens_failed = !primary_ray_dof(P, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
+			}
+			prim = false;
+		}
+		NextRayShadeIn hit;
+		hit.normal = hit_normal, hit.frag = ro, hit.color = ro, hit.roughness = 0.0, hit.metal = 0.0;
+		if (to_shade) {
+			const DevObject &o = lobjs[hit_obj];
+			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
+			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
+			if constexpr (GRID) hit.normal = mk(parked_normal[0], parked_normal[64], parked_normal[128]);
+		}
+		next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
+		bool cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
+		if (to_shade) {
+			depth++;
+			to_shade = false;
+			if (depth > P.bounce_limit) cut = true, has_ray = false;
+			else has_ray = true, new_ray = true;
+		}
 #if RMD_DIAG
 		if ((P.debug_flags & 8u) && P.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
-			const unsigned long long am = __ballot(alive), wm = __ballot(want);
-			const unsigned long long fm = __ballot(alive && terminal); // samples that ended before the intersection (bounce limit 0 / failed DoF ray)
-			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm)), atomicAdd(&P.debug_counters[15], (unsigned long long)__popcll(fm));
+			const unsigned long long am = __ballot(alive), wm = __ballot(has_ray && !lens_failed);
+			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm));
 		}
 #endif
-		// src/trace.rs:239
+		// ---------------- (A) src/trace.rs:239 — closest hit of every lane that has a ray
+		const bool want = has_ray && !lens_failed;
 		double t;
 		uint32_t sub;
 		int oi;
@@ -306,6 +337,8 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			oi = scene_intersect_wave<false>(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
 			complete = want;
 		}
+		bool terminal = lens_failed || cut;
+		V3 L = mk(0.0, 0.0, 0.0);
 		if (complete) {
 			if (LIST && path_obj) {
 				size_t pi = (size_t)list_idx * (RMD_PATH_STRIDE) + path_len;
@@ -317,7 +350,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 				terminal = true; // :242 miss -> radiance 0
 			} else {
 				const DevObject &o = lobjs[oi];
-				V3 frag = ro + rd * t; // :246
+				const V3 frag = ro + rd * t; // :246
 				if (o.material_kind == 2u) {
 					L = ld3(o.color); // :250-252 Emission
 					terminal = true;
@@ -331,31 +364,37 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 					} else {
 						normal = mk(0.0, 0.0, 0.0); // unreachable: a scene with grid objects runs the GRID instantiation
 					}
-#if RMD_DIAG
-					if ((P.debug_flags & 8u) && P.debug_counters) { const unsigned long long sm = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(sm)) atomicAdd(&P.debug_counters[13], (unsigned long long)__popcll(sm)), atomicAdd(&P.debug_counters[14], 1ull); }
-#endif
-					Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, P.key0, P.key1);
-					const V3 wgt = bounce_weight(b); // same factors as :281-282 / :315-318, multiplied forward
-					T = hadamard(T, wgt);
-					ro = b.next_origin, rd = b.next_dir;
-					new_ray = true;
-					depth++;
-					if (depth > P.bounce_limit) terminal = true; // :235-237: the recursive call returns 0 at once
+					// At the bounce limit the recursive call returns 0 at once (:235-237) and this depth's result is its weight times
+					// that zero (:281-282 / :315-318): exactly zero whenever the weight is finite, so the shading is not evaluated.
+					// A weight is non-finite only through a non-finite input — the Heron normal of a degenerate hit, a hit point
+					// at infinity — (then the reference's sample is NaN, and so is this one: the lane shades and multiplies by zero on
+					// its next trip), or through r1 = 0 exactly in the diffuse pdf (probability 2^-53 per path; there the reference
+					// returns NaN and this kernel 0).
+					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
+					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
+					if (depth == P.bounce_limit && finite_inputs) {
+						terminal = true; // L = 0
+					} else {
+						hit_obj = oi, hit_t = t;
+						if constexpr (GRID) parked_normal[0] = normal.x, parked_normal[64] = normal.y, parked_normal[128] = normal.z;
+						else hit_normal = normal;
+						to_shade = true;
+					}
 				}
 			}
+			has_ray = false;
 		}
-		if (alive && terminal) {
+		if (terminal) {
 			L = hadamard(T, L);
 			if constexpr (to_buffer) {
 				double *dst = P.sample_buf + (((size_t)wt * P.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * 3u;
 				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
-				alive = false; // the lane takes its next item at the top of the loop
 			} else {
 				acc = acc + L; // src/trace.rs:203
 				s++;
-				fresh = true;
-				if (s == s_end) alive = false;
 			}
+			has_ray = false;
+			need_sample = true;
 		}
 	}
 

@@ -116,10 +116,7 @@ __global__ __launch_bounds__(256) void wf_step(RenderParams P, WfState st, const
 					const DevGrid &g = grids[o.grid_index];
 					normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, as_global(g.tri_aux) + (size_t)sub * 4, frag);
 				}
-				Bounce b = shade(normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, P.key0, P.key1);
-				const V3 wgt = bounce_weight(b);
-				T = hadamard(T, wgt);
-				ro = b.next_origin, rd = b.next_dir;
+				shade(P, normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, ro, rd, T); // T <- T (.) weight, bounce ray
 				depth++;
 				if (depth > P.bounce_limit) terminal = true; // :235-237
 			}
