@@ -54,6 +54,14 @@ RMD_DEV double length(V3 a) { return sqrt64(dot(a, a)); }
 // instructions for the 13 + v_rcp_f64 of a division.  The result is the IEEE quotient for every divisor whose significand is
 // not all ones (the host stores NaN for those and for zero / extreme divisors, and the call sites then divide plainly);
 // tools/microbench/div_by_reciprocal_check.hip: 0 mismatches in 3.4e11 quotients.  a must be finite.
+// 1 / b to within an ulp or two: the hardware estimate and two Newton steps, without the scaling, special-case and final rounding
+// steps of an IEEE division (5 instructions for 11).  For values that only scale a sample's weight.
+RMD_DEV double fast_rcp(double b) {
+	double y = __builtin_amdgcn_rcp(b);
+	y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+	y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+	return y;
+}
 RMD_DEV double div_by(double a, double b, double r) {
 	const double q = a * r;
 	return __builtin_fma(__builtin_fma(-b, q, a), r, q);
@@ -458,37 +466,45 @@ RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const 
 	if (do_shade) {
 		const V3 normal = in.normal;
 		const double n_dot_sw = dot(normal, sw);
-		// :276 halfway of (sample_world, view); :307-308 halfway of (normalize(sample_world), view)
-		const V3 light = diffuse ? sw : normalize(sw);
-		const V3 halfway = normalize(light + view);
-		const double h_dot_v = dot(halfway, view);
-		const double fc = diffuse ? fmax(h_dot_v, 0.0) : h_dot_v; // :277 clamps, :309 does not
-		const V3 F = f0 + (mk(1.0, 1.0, 1.0) - f0) * pow5(1.0 - fc); // fresnel_schlick :384-386
-		V3 A;
-		double cosv, d;
-		if (diffuse) {
-			cosv = fmax(n_dot_sw, 0.0);                                        // :275
-			const V3 diffuse_part = (mk(1.0, 1.0, 1.0) - F) * (1.0 - in.metal); // :279-280
-			A = hadamard(diffuse_part, in.color);
-			d = prob_d * pdf_d; // :282
-		} else {
-			const double D = ggx_distribution(normal, halfway, in.roughness);
-			const double G = geometry_smith(normal, view, sw, in.roughness);
-			const V3 nominator = (D * G) * F;
-			const double denominator = 4.0 * dot(normal, view) * n_dot_sw + 0.001;
-			A = nominator * (1.0 / denominator); // :313 divides each channel; A only scales the weight, see below
-			cosv = n_dot_sw;                     // :306 unclamped
-			const double d2 = (D * dot(normal, halfway)) / (4.0 * h_dot_v) + 0.0001; // :317
-			d = (1.0 - prob_d) * d2;                                                 // :318 divides by (1 - prob_d), then by pdf
-		}
 		// Weight of the bounce.  trace() returns  diffuse (:281-282)  ((A (.) radiance) * cos) / (prob_d * pdf)
 		//                                         specular (:315-318) (((A (.) radiance) * cos) / (1 - prob_d)) / pdf
 		// i.e. radiance times a per-channel weight known before the recursive call; the kernel multiplies the weights forward
-		// into the throughput instead of applying them on the way back up.  The weight is formed with ONE
-		// reciprocal — (A * cos) * (1 / d) — instead of three or six correctly rounded divisions: a weight is a product of ~10
-		// rounded factors either way (<= 1 ulp more per bounce, against a 1e-9 bar), it never feeds a direction or a branch, and
-		// f64 division is the most expensive operation on this path (v_rcp_f64 issues at 1/3 rate + 10 FMAs).
-		const V3 wgt = (A * cosv) * (1.0 / d);
+		// into the throughput instead of applying them on the way back up.  A weight never feeds a
+		// direction or a branch — it only scales the sample — so it is evaluated as ONE quotient, vector x (N / Dn), with the
+		// reference's factors but not its seven correctly rounded divisions (f64 division is the most expensive operation on
+		// this path: v_rcp_f64 at quarter rate + 10 more instructions): <= a few ulp per bounce against the 1e-9 bar.
+		//   diffuse   (1 - F)(1 - metal) (.) color x  max(n.l, 0) / (prob_d * pdf)
+		//   specular  F x  D G (n.l) / ((4 (n.v)(n.l) + 0.001) (1 - prob_d) (D (n.h) / (4 (h.v)) + 0.0001))       with
+		//             D = a2 / Dd (:362-370), G = g1n g2n / (g1d g2d) (:372-382); Dd cancels:
+		//             N = a2 g1n g2n (n.l) 4(h.v),   Dn = g1d g2d (4 (n.v)(n.l) + 0.001) (1 - prob_d) (a2 (n.h) + 0.0001 Dd 4(h.v))
+		// :276 halfway of (sample_world, view); :307-308 normalise sample_world once more first — it is a unit vector already, the
+		// second normalisation moves it by at most an ulp, and only this weight would see that
+		const V3 halfway = normalize(sw + view);
+		const double h_dot_v = dot(halfway, view);
+		const double fc = diffuse ? fmax(h_dot_v, 0.0) : h_dot_v; // :277 clamps, :309 does not
+		const V3 F = f0 + (mk(1.0, 1.0, 1.0) - f0) * pow5(1.0 - fc); // fresnel_schlick :384-386
+		V3 vec;
+		double N, Dn;
+		if (diffuse) {
+			const V3 diffuse_part = (mk(1.0, 1.0, 1.0) - F) * (1.0 - in.metal); // :279-280
+			vec = hadamard(diffuse_part, in.color);
+			N = fmax(n_dot_sw, 0.0); // :275
+			Dn = prob_d * pdf_d;     // :282
+		} else {
+			const double a2 = in.roughness * in.roughness; // Q4
+			const double ndh = dot(normal, halfway);
+			const double den = (ndh * ndh) * (a2 - 1.0) + 1.0;
+			const double Dd = fmax(kPi * den * den, 1e-7); // :367-368
+			const double k = (in.roughness * in.roughness) / 8.0; // :374
+			const double g1n = fmax(dot(normal, view), 0.0), g2n = fmax(n_dot_sw, 0.0); // :373
+			const double g1d = g1n * (1.0 - k) + k, g2d = g2n * (1.0 - k) + k;         // :375-377
+			const double denominator = 4.0 * dot(normal, view) * n_dot_sw + 0.001;     // :312
+			const double hv4 = 4.0 * h_dot_v;
+			vec = F;
+			N = (((a2 * g1n) * g2n) * n_dot_sw) * hv4; // cos_theta = n.l unclamped (:306)
+			Dn = (((g1d * g2d) * denominator) * (1.0 - prob_d)) * (a2 * ndh + 0.0001 * (Dd * hv4));
+		}
+		const V3 wgt = vec * (N * fast_rcp(Dn));
 		T = hadamard(T, wgt);
 		ro = in.frag + normal * (diffuse ? 0.00001 : 0.0001); // :269 / :300
 		rd = sw;
