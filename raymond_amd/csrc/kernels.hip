@@ -239,7 +239,9 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	int hit_obj = -1;
 	double hit_t = 0.0;
 	V3 hit_normal = mk(0.0, 0.0, 1.0);
-	double *parked_normal = GRID ? reinterpret_cast<double *>(wave_lds) + lane : nullptr; // [0], [64], [128]
+	double *parked = GRID ? reinterpret_cast<double *>(wave_lds) + lane : nullptr; // normal at [0], [64], [128]; distance at [192]
+	int32_t *parked_obj = GRID ? reinterpret_cast<int32_t *>(wave_lds + 256u * sizeof(double)) + lane : nullptr;
+	static_assert(!GRID || sizeof(WalkScratch) >= 256u * sizeof(double) + 64u * sizeof(int32_t), "the walk scratch holds a wave's parked hits");
 	// grid scenes: a ray's closest plane/sphere hit while the lane waits for the walk that settles the grids (see intersect_simple)
 	bool new_ray = false, waiting = false;
 	uint32_t trips_since_walk = 0; // wave-uniform
@@ -293,10 +295,10 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		NextRayShadeIn hit;
 		hit.normal = hit_normal, hit.frag = ro, hit.color = ro, hit.roughness = 0.0, hit.metal = 0.0;
 		if (to_shade) {
+			if constexpr (GRID) hit.normal = mk(parked[0], parked[64], parked[128]), hit_t = parked[192], hit_obj = parked_obj[0];
 			const DevObject &o = lobjs[hit_obj];
 			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
 			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
-			if constexpr (GRID) hit.normal = mk(parked_normal[0], parked_normal[64], parked_normal[128]);
 		}
 		next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
 		bool cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
@@ -375,9 +377,8 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 					if (depth == P.bounce_limit && finite_inputs) {
 						terminal = true; // L = 0
 					} else {
-						hit_obj = oi, hit_t = t;
-						if constexpr (GRID) parked_normal[0] = normal.x, parked_normal[64] = normal.y, parked_normal[128] = normal.z;
-						else hit_normal = normal;
+						if constexpr (GRID) parked[0] = normal.x, parked[64] = normal.y, parked[128] = normal.z, parked[192] = t, parked_obj[0] = oi;
+						else hit_normal = normal, hit_obj = oi, hit_t = t;
 						to_shade = true;
 					}
 				}
