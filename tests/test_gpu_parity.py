@@ -269,6 +269,46 @@ def test_scene_intersect_spheres(gpu_ctx, oracle):
     ds.close()
 
 
+def test_planes_special_rays_bit_exact(gpu_ctx, oracle):
+    """Scene::intersect over axis-aligned, non-unit and slanted planes plus a sphere: closest object and distance bit for bit,
+    including direction components with an all-ones significand, origins exactly on a plane, zero / tiny / negative-zero
+    direction components and -0.0 in a normal.  (Written for a variant that intersected axis-aligned planes through one shared
+    reciprocal per axis — bit-exact, fewer instructions, but slower: DESIGN.md "measured and rejected".)"""
+    from raymond_amd.scene import Material, Object, Plane, Scene, Sphere
+
+    sc = Scene()
+    grey = Material.Diffuse((0.5, 0.5, 0.5), 0.5)
+    for origin, normal in (
+        ((0.0, -1.0, 0.0), (0.0, 1.0, 0.0)), ((0.0, 2.0, 0.0), (-0.0, -1.0, 0.0)), ((0.0, 0.0, -2.0), (0.0, -0.0, 1.0)),
+        ((0.0, 0.0, 5.0), (0.0, 0.0, -1.0)), ((-2.0, 0.0, 0.0), (1.0, 0.0, -0.0)), ((2.0, 0.0, 0.0), (-1.0, 0.0, 0.0)),
+        ((0.0, 1.5, 0.0), (0.0, -2.0, 0.0)),                      # axis-aligned but not unit: plain test
+        ((0.0, 0.0, 4.0), (0.3, 0.1, -0.9)),                      # slanted: plain test
+        ((7.0, 1.75, -3.0), (0.0, -1.0, 0.0)),                    # a second plane on the y axis, in front of the ceiling
+    ):
+        sc.objects.append(Object(Plane(origin, normal), grey))
+    sc.objects.append(Object(Sphere((0.3, 0.2, 2.0), 0.4), grey))
+    rng = np.random.default_rng(21)
+    rays = rays_toward(rng, 3 * N, (0, 0.5, 1.5), 2.5)
+    d = rays[:, 3:]
+    ones = np.nextafter(1.0, 0.0)  # 0x3FEFFFFFFFFFFFFF: all-ones significand, div_by's one unsupported divisor class
+    d[:64] = [0.0, -ones, 0.0]
+    d[64:128, 0] = np.nextafter(0.5, 0.0)
+    d[128:192, 2] = -np.nextafter(0.25, 0.0)
+    d[192:256, 1] = 0.0
+    d[256:320, 0] = -0.0
+    d[320:384, 2] = 1e-7   # faces no z plane by the 1e-6 rule
+    d[384:448, 2] = 1.1e-6
+    rays[448:512, 1] = -1.0  # origin on the floor plane: numerator zero
+    rays[512:576, 0] = 2.0   # origin on the right wall
+    rays[576:640, :3] = [0.0, 1.75, 0.0]
+    dobj, dt, dsub = probe.scene_intersect(gpu_ctx, render.DeviceScene(gpu_ctx, sc), rays)
+    oobj, ot, osub = oracle.OracleScene(sc).scene_intersect(rays)
+    assert np.array_equal(dobj, oobj)
+    m = oobj >= 0
+    assert np.array_equal(dt[m].view(np.uint64), ot[m].view(np.uint64))
+    assert len(set(oobj.tolist())) >= 8 and (oobj[:64] >= 0).all()
+
+
 def test_grid_walk(gpu_ctx, oracle, small_mesh_scene):
     """AccGrid::intersects incl. origins inside the box, on the max side (Q6) and axis-parallel rays (Q8)."""
     sc = small_mesh_scene
