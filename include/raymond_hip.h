@@ -175,10 +175,13 @@ enum {
 	RMD_TUNE_SAMPLE_SPLIT = 0, /* RMD_SAMPLE_SPLIT: waves a wave tile's sample range is split over (0 = automatic)  */
 	RMD_TUNE_WALK_BATCH = 1,   /* RMD_WALK_BATCH: lanes of a wave that wait for a grid walk before one is run        */
 	RMD_TUNE_MASK_BUDGET = 2,  /* RMD_MASK_BUDGET: LDS bytes for the grids' occupancy masks (read by rmd_scene_create) */
-	RMD_TUNE_GRID_MODE = 3,    /* RMD_GRID_MODE=wavefront -> 1: streaming pipeline for grid scenes; 0 = megakernel    */
+	RMD_TUNE_GRID_MODE = 3,    /* RMD_GRID_MODE: schedule of scenes with grids.  0 = megakernel (one wave = 64 paths + their
+	                              walks); 1 / "wavefront" = streaming pipeline with path state in HBM; 2 / "cuqueue" = persistent
+	                              workgroups of tracer and walker waves around a ray queue in the CU's LDS                  */
 	RMD_TUNE_SCRATCH_CAP_MB = 4, /* RMD_SCRATCH_CAP_MB: cap of the per-sample scratch of split launches, MiB (0 = a quarter of HBM);
 	                              a launch whose samples do not fit runs as several passes                              */
-	RMD_TUNE_COUNT = 5
+	RMD_TUNE_CUQ_TRACERS = 5,  /* RMD_CUQ_TRACERS: tracer waves among the 16 of a CU in grid mode 2 (0 = the library's choice)  */
+	RMD_TUNE_COUNT = 6
 };
 rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value);
 rmd_status rmd_context_get_tunable(const rmd_context *ctx, uint32_t key, int64_t *out_value);

@@ -66,7 +66,8 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_MASK_BUDGET] = env_int("RMD_MASK_BUDGET");
 		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
 		const char *mode = std::getenv("RMD_GRID_MODE");
-		ctx->tunable[RMD_TUNE_GRID_MODE] = (mode && std::strcmp(mode, "wavefront") == 0) ? 1 : 0;
+		ctx->tunable[RMD_TUNE_GRID_MODE] = !mode ? 0 : (std::strcmp(mode, "wavefront") == 0 || std::strcmp(mode, "1") == 0) ? 1 : (std::strcmp(mode, "cuqueue") == 0 || std::strcmp(mode, "2") == 0) ? 2 : 0;
+		ctx->tunable[RMD_TUNE_CUQ_TRACERS] = env_int("RMD_CUQ_TRACERS");
 #if RMD_DIAG
 		ctx->debug_flags = (uint32_t)env_int("RMD_DEBUG"); // DIAG builds only: 1 | 2 are timing ablations that change results, 8 | 16 count events
 #endif
@@ -189,6 +190,7 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->d_sample_buf) (void)hipFree(ctx->d_sample_buf);
 	if (ctx->d_debug_counters) (void)hipFree(ctx->d_debug_counters);
 	if (ctx->d_wavefront_ws) (void)hipFree(ctx->d_wavefront_ws);
+	if (ctx->d_cuq_ws) (void)hipFree(ctx->d_cuq_ws);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -457,14 +459,18 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		return RMD_OK;
 	}
 	const uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
+	// grid mode 2: persistent tracer / walker workgroups (cuqueue.hip); it writes per-sample output, i.e. it needs a split launch
+	const bool use_cuq = scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 2 && split > 1u && !(P.debug_flags & 16u);
+	if (use_cuq && !ctx->d_cuq_ws) RMD_HIP(ctx, hipMalloc(&ctx->d_cuq_ws, rmd::cuq_workspace_bytes()));
 	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes.  It may take a quarter of the
 	// device's HBM (72 GiB of 288: the whole C3 frame at 500 spp is 24.9 GB, one launch); what does not fit runs as several passes
 	uint32_t per_pass = P.sample_count;
 	if (split > 1u) {
-		const size_t bytes_per_sample = (size_t)P.n_work * 64u * 3u * sizeof(double);
+		const size_t bytes_per_sample = (size_t)P.n_work * 64u * rmd::kSampleStride * sizeof(double);
 		size_t cap = ctx->hbm_bytes / 4;
 		if (ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] > 0) cap = (size_t)ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] << 20;
 		if (bytes_per_sample * per_pass > cap) per_pass = (uint32_t)(cap / bytes_per_sample);
+		if (use_cuq && (uint64_t)P.n_work * 64u * per_pass > 0xFFFFFFFFull) per_pass = (uint32_t)(0xFFFFFFFFull / ((uint64_t)P.n_work * 64u)); // 32-bit sample slots
 		if (per_pass < 8u) per_pass = 8u;
 		const size_t need = bytes_per_sample * per_pass;
 		if (need > ctx->sample_buf_bytes) {
@@ -481,6 +487,11 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		Q.sample_count = settings->sample_count - done < per_pass ? (uint32_t)(settings->sample_count - done) : per_pass;
 		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
 		Q.sample_buf = ctx->d_sample_buf;
+		if (use_cuq && Q.split_k > 1u) {
+			RMD_HIP(ctx, rmd::launch_render_cuq(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, ctx->d_cuq_ws, ctx->n_cus,
+			                                    (uint32_t)ctx->tunable[RMD_TUNE_CUQ_TRACERS]));
+			continue;
+		}
 		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev));
 		if (settings->sample_count == 0) break;
 	}
@@ -503,7 +514,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value) {
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: null context");
 	if (key >= RMD_TUNE_COUNT || value < 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: unknown key or negative value");
-	if (key == RMD_TUNE_GRID_MODE && value > 1) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: grid mode is 0 or 1");
+	if (key == RMD_TUNE_GRID_MODE && value > 2) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: grid mode is 0, 1 or 2");
+	if (key == RMD_TUNE_CUQ_TRACERS && value > 15) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: 1..15 tracer waves");
 	ctx->tunable[key] = value;
 	return RMD_OK;
 }

@@ -17,6 +17,7 @@
 #include "device_core.hpp"
 #include "grid_walk.hpp"
 #include "launch.hpp"
+#include "scene_split.hpp"
 
 namespace rmd {
 
@@ -71,49 +72,6 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	return best;
 }
 
-// The same scan in two parts, for the render loop of a scene with grids.  Scene::intersect keeps the first object on
-// distance ties, i.e. it returns the lexicographic minimum of (distance, object index) — so the objects may be visited
-// in any order as long as candidates are merged with that rule.  intersect_simple() visits planes and spheres and
-// reports whether the ray enters any grid's bounding box (acc_grid.rs:90); intersect_grids() later runs the cooperative
-// walks of the grid objects for the lanes that do, and merges.  Splitting the scan lets a lane WAIT for its walk until
-// enough other lanes of the wave need one too (RenderParams::walk_batch): a walk phase costs about the same for 15 rays as for 45,
-// because the wave steps until its longest walk ends either way.
-RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return t < t_best || (t == t_best && obj < obj_best); }
-RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, bool want, V3 ro, V3 rd,
-                              double &closest, int &best) {
-	closest = kFMax, best = -1;
-	bool enters = false;
-	for (uint32_t i = 0; i < n_objects; i++) {
-		const DevObject &o = objs[i];
-		double t = 0.0;
-		bool hit = false;
-		if (o.geometry_kind == 0u) {
-			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
-		} else if (o.geometry_kind == 1u) {
-			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
-		} else {
-			const DevGrid &g = grids[o.grid_index];
-			double t_outer;
-			if (want && aabb_intersect(ld3(g.bbox_min), ld3(g.bbox_max), ro, rd, t_outer)) enters = true;
-		}
-		if (want && hit && t < closest) closest = t, best = (int)i; // index order + strict '<' = the lexicographic minimum so far
-	}
-	return enters;
-}
-RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, const uint32_t *lds_masks,
-                             WalkScratch &scr, bool walkers, V3 ro, V3 rd, double &closest, int &best, uint32_t &sub, uint32_t debug_flags,
-                             unsigned long long *dbg) {
-	for (uint32_t i = 0; i < n_objects; i++) {
-		const DevObject &o = objs[i];
-		if (o.geometry_kind != 2u) continue; // uniform
-		const DevGrid &g = grids[o.grid_index];
-		bool hit = false;
-		double t = 0.0;
-		uint32_t tri = 0;
-		grid_intersect_wave(g, lds_masks + g.mask_lds_word, scr, walkers, ro, rd, hit, t, tri, debug_flags, dbg);
-		if (walkers && hit && lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = tri;
-	}
-}
 // A walk is run when RenderParams::walk_batch lanes of the wave wait for one (launch.hpp: kWalkBatchDefault = 32, measured best
 // of 12..56 on the benchmark mesh),
 // ... or fewer than this many lanes could do anything else on this trip (a trip costs the same for 5 lanes as for 50)
@@ -388,7 +346,9 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		if (terminal) {
 			L = hadamard(T, L);
 			if constexpr (to_buffer) {
-				double *dst = P.sample_buf + (((size_t)wt * P.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * 3u;
+				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
+				// sample's store travels alone, and a 24-byte store that straddles sectors was costing 2.7x its size in L2 write-backs
+				double *dst = P.sample_buf + (((size_t)wt * P.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
 				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
 			} else {
 				acc = acc + L; // src/trace.rs:203
@@ -417,10 +377,10 @@ __global__ __launch_bounds__(64) void sum_kernel(RenderParams P, const WaveTile 
 	if (lx >= t.w || ly >= t.h) return;
 	const size_t pix = ((size_t)(t.x0 + lx) + (size_t)(t.y0 + ly) * P.W) * 3;
 	V3 acc = ld3(out + pix);
-	const double *src = buf + ((size_t)wt * P.sample_count * 64u + lane) * 3;
+	const double *src = buf + ((size_t)wt * P.sample_count * 64u + lane) * kSampleStride;
 	for (uint32_t s = 0; s < P.sample_count; s++) {
 		acc = acc + ld3(src);
-		src += 64u * 3u;
+		src += 64u * kSampleStride;
 	}
 	out[pix + 0] = acc.x, out[pix + 1] = acc.y, out[pix + 2] = acc.z;
 }
@@ -616,6 +576,12 @@ hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const 
 	else e = buffered ? launch_render<kModeTilesBuffered, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
 	                  : launch_render<kModeTiles, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
 	if (e != hipSuccess || !buffered) return e;
+	hipLaunchKernelGGL(sum_kernel, dim3(P.n_work), dim3(64), 0, stream, P, wave_tiles, (const double *)P.sample_buf, accum);
+	return hipGetLastError();
+}
+
+hipError_t launch_sum(hipStream_t stream, const RenderParams &P, const WaveTile *wave_tiles, double *accum) {
+	if (P.n_work == 0) return hipSuccess;
 	hipLaunchKernelGGL(sum_kernel, dim3(P.n_work), dim3(64), 0, stream, P, wave_tiles, (const double *)P.sample_buf, accum);
 	return hipGetLastError();
 }

@@ -35,6 +35,8 @@ enum ProbeOp {
 constexpr size_t kLdsBudgetBytes = 160u * 1024u;
 // LDS bytes reserved for the grids' occupancy masks (shared by the waves of a workgroup)
 constexpr size_t kMaskBudgetBytes = 48u * 1024u;
+// doubles per entry of the per-sample scratch of split launches: r, g, b and one of padding = one 32-byte sector
+constexpr uint32_t kSampleStride = 4;
 // walk batching (kernels.hip): lanes of a wave that must be waiting for a grid walk before one is run
 constexpr uint32_t kWalkBatchDefault = 32;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
@@ -51,6 +53,13 @@ hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const 
                                const WaveTile *wave_tiles, double *accum);
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub);
+// pixel += the per-sample radiance of a split launch, in sample order (kernels.hip: sum_kernel)
+hipError_t launch_sum(hipStream_t stream, const RenderParams &P, const WaveTile *wave_tiles, double *accum);
+// Grid scenes through the CU-level ray queue (cuqueue.hip): persistent workgroups of tracer and walker waves; P.split_k, P.sample_buf
+// as for a split launch.  workspace: cuq_workspace_bytes() of device memory.
+size_t cuq_workspace_bytes();
+hipError_t launch_render_cuq(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const WaveTile *wave_tiles,
+                             double *accum, void *workspace, uint32_t n_cus, uint32_t n_tracers);
 // Streaming evaluation for scenes with grids (wavefront.hip).  Synchronises the stream while it polls for completion.
 size_t wavefront_workspace_bytes(uint32_t n_wave_tiles);
 hipError_t launch_wavefront(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const WaveTile *wave_tiles,

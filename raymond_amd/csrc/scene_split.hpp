@@ -1,0 +1,52 @@
+// Scene::intersect (core/src/scene.rs:54-74) in two parts, shared by the schedules for scenes with grids (kernels.hip, cuqueue.hip).
+#pragma once
+#include "device_core.hpp"
+#include "grid_walk.hpp"
+
+namespace rmd {
+
+// The same scan in two parts, for the render loop of a scene with grids.  Scene::intersect keeps the first object on
+// distance ties, i.e. it returns the lexicographic minimum of (distance, object index) — so the objects may be visited
+// in any order as long as candidates are merged with that rule.  intersect_simple() visits planes and spheres and
+// reports whether the ray enters any grid's bounding box (acc_grid.rs:90); intersect_grids() later runs the cooperative
+// walks of the grid objects for the lanes that do, and merges.  Splitting the scan lets a lane WAIT for its walk until
+// enough other lanes of the wave need one too (RenderParams::walk_batch): a walk phase costs about the same for 15 rays as for 45,
+// because the wave steps until its longest walk ends either way.
+RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return t < t_best || (t == t_best && obj < obj_best); }
+RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, bool want, V3 ro, V3 rd,
+                              double &closest, int &best) {
+	closest = kFMax, best = -1;
+	bool enters = false;
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const DevObject &o = objs[i];
+		double t = 0.0;
+		bool hit = false;
+		if (o.geometry_kind == 0u) {
+			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
+		} else if (o.geometry_kind == 1u) {
+			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
+		} else {
+			const DevGrid &g = grids[o.grid_index];
+			double t_outer;
+			if (want && aabb_intersect(ld3(g.bbox_min), ld3(g.bbox_max), ro, rd, t_outer)) enters = true;
+		}
+		if (want && hit && t < closest) closest = t, best = (int)i; // index order + strict '<' = the lexicographic minimum so far
+	}
+	return enters;
+}
+RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, const uint32_t *lds_masks,
+                             WalkScratch &scr, bool walkers, V3 ro, V3 rd, double &closest, int &best, uint32_t &sub, uint32_t debug_flags,
+                             unsigned long long *dbg) {
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const DevObject &o = objs[i];
+		if (o.geometry_kind != 2u) continue; // uniform
+		const DevGrid &g = grids[o.grid_index];
+		bool hit = false;
+		double t = 0.0;
+		uint32_t tri = 0;
+		grid_intersect_wave(g, lds_masks + g.mask_lds_word, scr, walkers, ro, rd, hit, t, tri, debug_flags, dbg);
+		if (walkers && hit && lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = tri;
+	}
+}
+
+} // namespace rmd

@@ -699,3 +699,42 @@ def test_wavefront_mode_is_bit_identical(gpu_ctx, small_mesh_scene):
             assert (out["megakernel"] != base).any()
         fb.close()
     ds.close()
+
+
+def test_cu_queue_mode_is_bit_identical(gpu_ctx, small_mesh_scene, oracle):
+    """Grid mode 2 (cuqueue.hip): persistent workgroups whose waves split into tracers (paths; a ray that enters a grid's box is
+    parked in LDS and queued) and walkers (pop a ray, walk it, merge the hit, pop the next).  Same arithmetic, same per-sample
+    output => the frame must equal the megakernel's bit for bit: thin lens, += on a pre-filled buffer, ragged tiles, a
+    sub-range of samples, bounce limits 1 and 8, every split of the 16 waves, and a scene with two grids."""
+    from raymond_amd.scene import AccGrid, Grid, Material, Object, Plane, Scene, Sphere
+
+    two = Scene()
+    two.objects.append(Object(Grid(AccGrid.build_from_mesh(scenes.lumpy_sphere_mesh(6, (0.9, 0.9, 0.5), (-0.6, -0.2, 2.6)))), Material.Metal((1.0, 1.0, 0.1), 0.15)))
+    two.objects.append(Object(Plane((0.0, -1.0, 0.0), (0.0, 1.0, 0.0)), Material.Diffuse((0.75, 0.75, 0.75), 0.5)))
+    two.objects.append(Object(Grid(AccGrid.build_from_mesh(scenes.lumpy_sphere_mesh(5, (1.0, 1.1, 0.7), (0.5, 0.0, 2.9)))), Material.Diffuse((0.2, 0.8, 0.3), 0.4)))
+    two.objects.append(Object(Plane((0.0, 2.0, 0.0), (0.0, -1.0, 0.0)), Material.Emission((1.5, 1.5, 1.5))))
+    cases = [
+        (small_mesh_scene, Settings(scenes.camera(200, 120), sample_count=9, bounce_limit=5, seed=5), 0, 9, 0),
+        (small_mesh_scene, Settings(scenes.camera(200, 120, aperture_radius=0.5), sample_count=12, bounce_limit=8, seed=6, use_dof=True), 3, 9, 4),
+        (small_mesh_scene, Settings(scenes.camera(64, 40), sample_count=8, bounce_limit=1, seed=8), 0, 8, 12),
+        (two, Settings(scenes.camera(160, 96), sample_count=8, bounce_limit=5, seed=9), 0, 8, 6),
+    ]
+    for sc, st, begin, count, tracers in cases:
+        cam = st.camera_settings
+        W, H = cam.backbuffer_width, cam.backbuffer_height
+        tiles = generate_tiles(W, H, (32, 32))
+        base = np.random.default_rng(1).uniform(0, 1, (H, W, 3))
+        ds = render.DeviceScene(gpu_ctx, sc)
+        fb = render.Framebuffer(gpu_ctx, W, H)
+        out = {}
+        for mode in (0, 2):
+            gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, mode), gpu_ctx.set_tunable(abi.RMD_TUNE_CUQ_TRACERS, tracers)
+            try:
+                fb.upload(base)
+                render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, begin, count)
+                out[mode] = fb.download()
+            finally:
+                gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_CUQ_TRACERS, 0)
+        assert out[2].tobytes() == out[0].tobytes(), (W, H, tracers)
+        assert (out[0] != base).any()
+        fb.close(), ds.close()

@@ -235,7 +235,7 @@ def test_c4_shaped_launch(gpu_ctx, oracle, dragon):
     ok = rel_close(got, acc, 1e-9).all(axis=1)
     assert ok.mean() >= 0.99, ok.mean()
     # (b) two passes of 8 samples: the cap is sized so that 16 samples do not fit and 8 do
-    bytes_per_sample = (W // 8) * (H // 8) * 64 * 24
+    bytes_per_sample = (W // 8) * (H // 8) * 64 * 32  # one 32-byte sector per (pixel, sample)
     gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, (bytes_per_sample * 12) >> 20)
     try:
         fb.zero()
