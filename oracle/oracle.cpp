@@ -2,12 +2,13 @@
  * oracle.cpp — CPU restatement (C++17, binary64) of Nyrox/raymond's per-pixel radiance loop.
  *
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  Parity is UNPINNED by reference tests: the
- * reference ships none and cannot be built here.  Every function cites the reference
+ * reference ships none and cannot be built here; oracle.h lists what pins it instead (the
+ * reference's own render at its own 500 spp, its own mesh files).  Every function cites the reference
  * file:line it restates (paths relative to /root/reference).  Recursion, evaluation order
  * and every quirk are kept literal; the only additions are
  *   - the RNG: rand::random::<f64>() (unseedable thread_rng) is replaced by counter-based
- *     Philox4x32-10 keyed by (seed; pixel, sample, draw), so that a GPU kernel can consume
- *     the identical stream;
+ *     Philox4x32-10 keyed by seed with counter (pixel, sample, block), one block per consumer
+ *     (include/raymond_hip.h "RNG"), so that a GPU kernel can consume the identical stream;
  *   - failure behaviour: where the reference panics (cast overflow, unwrap on None) the
  *     oracle returns a miss / zero sample and says so at the site.
  * cgmath 0.17 semantics relied on (crate source not vendored in the reference):

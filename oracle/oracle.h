@@ -7,12 +7,23 @@
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  * Nothing under raymond_amd/ links, imports or calls it.
  *
- * PARITY UNPINNED by reference tests: the reference has no tests, fixtures or
- * golden vectors for this path and cannot be compiled here (no Rust toolchain),
- * so the restatement is pinned only by (a) the Random123 known-answer vectors
- * for the RNG, (b) hand-derived known answers per primitive, and (c) a
- * statistical comparison with examples/ReflectiveSpheres.png (block means
- * committed under tests/golden/).
+ * PARITY UNPINNED by reference TESTS: the reference has no tests, fixtures or
+ * golden vectors for this path and cannot be compiled here (no Rust toolchain).
+ * What the reference does hold pins the restatement as far as it reaches
+ * (tests/test_oracle_golden.py, tests/test_ref_meshes.py):
+ *   (a) its one render of the spheres scene, examples/ReflectiveSpheres.png (500 spp):
+ *       the oracle's 500-spp frame differs from it by Monte-Carlo noise and nothing
+ *       else — block means 0.44 of 255 apart where two oracle half-frames predict
+ *       0.44, no region biased by more than 0.1 — which covers scene, camera, the
+ *       BRDF and sampling code, and the output stage;
+ *   (b) its mesh assets (assets/meshes, five PLY files): loader, bake_transform, bounds and
+ *       the grid build agree bit for bit with a third, plain-Python implementation
+ *       run over those files (tools/gen_ref_fixtures.py), including the reference's
+ *       out-of-bounds panic on suzanne.ply;
+ *   (c) the Random123 known-answer vectors for the RNG, and hand-derived known
+ *       answers per primitive.
+ * Nothing reference-held constrains the DDA walk's cell sequence, the Heron normals
+ * or the thin lens beyond their agreement with the source text.
  *
  * The scene POD types are shared with the product header (inputs only).
  */
