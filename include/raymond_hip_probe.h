@@ -1,5 +1,6 @@
 /*
- * raymond_hip_probe.h — diagnostic entry points of libraymond_hip.so.
+ * raymond_hip_probe.h — diagnostic entry points, in libraymond_hip_probe.so (a separate library that links against
+ * libraymond_hip.so and takes its rmd_context / rmd_scene handles; the product library exports none of these).
  *
  * Each probe runs ONE device function of the hot path on the GPU over a batch of host-supplied
  * inputs, so the parity tests can compare it with the CPU oracle function by function

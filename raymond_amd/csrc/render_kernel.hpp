@@ -1,0 +1,374 @@
+// The render kernel (all instantiations) and its launcher template: included by kernels.hip (tile modes, the product's hot path)
+// and by probe_kernels.hip (list mode: the same code driven by an explicit (x, y, sample) list, for the parity probes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_core.hpp"
+#include "grid_walk.hpp"
+#include "launch.hpp"
+#include "scene_split.hpp"
+
+namespace rmd {
+
+// LDS per wave: the cooperative-walk scratch, only when the scene has grids.
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) : 0; }
+
+// Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
+// reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
+// spreads every image region over all 8 XCDs: the mesh region costs ~10x a wall region per tile, and a mapping that
+// hands each XCD one contiguous band of the image leaves most XCDs idle while two or three grind through the mesh
+// (measured: 2x slower).  Balance beats L2 locality here — the scene (tens of MB) lives in L2 + Infinity Cache anyway.
+RMD_DEV uint32_t work_item_of_block(uint32_t b, uint32_t nb) {
+	(void)nb;
+	return b;
+}
+
+// core/src/scene.rs:54-74: linear closest hit over the objects; strict '<' keeps the first object on ties.
+// Wave-level: called by all 64 lanes in uniform control flow, `want` marks the lanes that carry a ray.  The object
+// table is indexed uniformly (scalar loads); planes and spheres are tested per lane, a grid object runs the
+// wave-cooperative walk.
+template <bool GRID>
+RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids,
+                                 const uint32_t *lds_masks, WalkScratch &scr, bool want, V3 ro, V3 rd, double &t_best, uint32_t &sub_best,
+                                 uint32_t debug_flags = 0, unsigned long long *dbg = nullptr) {
+	double closest = kFMax;
+	int best = -1;
+	uint32_t sub = 0;
+	for (uint32_t i = 0; i < n_objects; i++) {
+		const DevObject &o = objs[i];
+		double t = 0.0;
+		uint32_t tri = 0;
+		bool hit = false;
+		if (o.geometry_kind == 0u) {
+			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
+		} else if (o.geometry_kind == 1u) {
+			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
+		} else if constexpr (GRID) {
+			const DevGrid &g = grids[o.grid_index];
+			const uint32_t *mask = (lds_masks && g.mask_lds_word != 0xFFFFFFFFu) ? lds_masks + g.mask_lds_word : nullptr;
+			grid_intersect_wave(g, mask, scr, want, ro, rd, hit, t, tri, debug_flags, dbg);
+		}
+		if (want && hit) {
+			if (t < closest) {
+				closest = t;
+				best = (int)i;
+				sub = tri;
+			}
+		}
+	}
+	t_best = closest;
+	sub_best = sub;
+	return best;
+}
+
+// A walk is run when RenderParams::walk_batch lanes of the wave wait for one (launch.hpp: kWalkBatchDefault = 32, measured best
+// of 12..56 on the benchmark mesh),
+// ... or fewer than this many lanes could do anything else on this trip (a trip costs the same for 5 lanes as for 50)
+#ifndef RMD_WALK_MIN_RUNNABLE
+#define RMD_WALK_MIN_RUNNABLE 16
+#endif
+constexpr uint32_t kWalkMinRunnable = RMD_WALK_MIN_RUNNABLE;
+// ... or this many trips have passed since the wave's last walk (scenes where few rays reach a grid: bounds the wait)
+#ifndef RMD_WALK_MAX_WAIT
+#define RMD_WALK_MAX_WAIT 4
+#endif
+constexpr uint32_t kWalkMaxWait = RMD_WALK_MAX_WAIT;
+
+// Occupancy targets (waves per SIMD), measured on MI355X: the grid walk is latency-bound and gains 1.6x from 4 waves/SIMD
+// (128 VGPRs, a few dozen spills) over 2; the grid-less kernel is VALU-bound and is fastest at 3 (168 VGPRs).
+#ifndef RMD_GRID_MINW
+#define RMD_GRID_MINW 4
+#endif
+#ifndef RMD_NOGRID_MINW
+#define RMD_NOGRID_MINW 3
+#endif
+// MODE: 0 = wave tiles, the lane keeps its pixel's sum (one wave per tile); 1 = wave tiles with the samples of a tile split
+// over several waves, every sample's radiance stored to the sample buffer for sum_kernel; 2 = explicit (x, y, sample) list.
+// (A template parameter rather than a launch parameter: the buffer mode then carries no accumulator and the direct mode no
+// buffer addressing — the grid kernel runs at its register limit.)
+enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
+template <int MODE, bool GRID>
+__global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_MINW : RMD_NOGRID_MINW) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
+                                                     const DevGrid *__restrict__ grids, const void *__restrict__ work,
+                                                     double *__restrict__ out, int32_t *__restrict__ path_obj,
+                                                     uint32_t *__restrict__ path_sub) {
+	constexpr bool LIST = MODE == kModeList;
+	extern __shared__ __align__(16) unsigned char smem[];
+	// LDS: [object table][grid occupancy masks][one walk scratch per wave]
+	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
+	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
+	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
+	                          (size_t)wave * wave_lds_bytes(P.n_grids);
+	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
+
+	// stage the object table and the occupancy masks: coalesced, once per workgroup
+	{
+		const double *src = reinterpret_cast<const double *>(objs);
+		double *dst = reinterpret_cast<double *>(lobjs);
+		for (uint32_t i = tid; i < P.n_objects * 16u; i += blockDim.x) dst[i] = src[i];
+		for (uint32_t gi = 0; gi < P.n_grids; gi++) {
+			const DevGrid &g = grids[gi];
+			if (g.mask_lds_word == 0xFFFFFFFFu) continue;
+			for (uint32_t i = tid; i < g.mask_n_words; i += blockDim.x) lmasks[g.mask_lds_word + i] = as_global(g.mask_words)[i];
+		}
+	}
+	__syncthreads(); // the only workgroup barrier: from here on every wave runs on its own
+	const uint32_t *lds_masks = P.mask_words_total ? lmasks : nullptr;
+
+	constexpr bool to_buffer = MODE == kModeTilesBuffered;
+	// Per-lane work.  LIST: one (x, y, sample) entry.  Tiles, direct mode: lane = pixel, samples s .. s_end-1 one after the
+	// other, the lane keeps the sum.  Tiles, buffered mode: the wave owns a sample range of its tile and its (pixel, sample)
+	// pairs form a pool — item k is pixel slot k % 64 of sample k / 64 — from which a lane whose path has ended takes the
+	// next item, so no lane sits out while the longest pixel of the tile finishes (which lane computes a sample has no
+	// influence on its value: the RNG is keyed by pixel and sample, and sum_kernel adds the samples in order).
+	uint32_t x = 0, y = 0, s = 0, s_end = 0;
+	bool alive = false; // the lane has samples left (direct / list) — buffered mode: the lane holds a pool item
+	size_t out_index = 0;
+	uint32_t list_idx = 0;
+	WaveTile tile = {};
+	uint32_t wt = 0, pool_first = 0, pool_items = 0, next_item = 0; // wave-uniform (buffered mode)
+	uint32_t item = 0;                                               // this lane's pool item (buffered mode)
+	if (LIST) {
+		list_idx = (blockIdx.x * waves_per_wg + wave) * 64u + lane;
+		alive = list_idx < P.n_work;
+		ListWork w = reinterpret_cast<const ListWork *>(work)[alive ? list_idx : 0];
+		x = w.x, y = w.y, s = w.sample, s_end = w.sample + 1u;
+		out_index = (size_t)list_idx * 3;
+	} else {
+		// work item = (wave tile, sample sub-range): with split_k > 1 the samples of a tile are spread over split_k
+		// waves (neighbouring waves, same tile) that store every sample's radiance to the sample buffer; sum_kernel then
+		// adds them to the pixel in sample order, so the result is the same sequential sum as with one wave per tile
+		const uint32_t work_item = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
+		const uint32_t split = to_buffer ? P.split_k : 1u;
+		wt = work_item / split;
+		const uint32_t part = work_item % split;
+		const bool have = wt < P.n_work;
+		tile = reinterpret_cast<const WaveTile *>(work)[have ? wt : 0];
+		const uint32_t per_part = (P.sample_count + split - 1u) / split;
+		const uint32_t s_lo = part * per_part < P.sample_count ? part * per_part : P.sample_count;
+		const uint32_t s_hi = s_lo + per_part < P.sample_count ? s_lo + per_part : P.sample_count;
+		if constexpr (to_buffer) {
+			pool_first = s_lo;
+			pool_items = have ? (s_hi - s_lo) * 64u : 0u;
+		} else {
+			const uint32_t lx = lane & 7u, ly = lane >> 3;
+			alive = have && lx < tile.w && ly < tile.h && s_hi > s_lo;
+			x = tile.x0 + lx, y = tile.y0 + ly;
+			s = P.sample_begin + s_lo, s_end = P.sample_begin + s_hi;
+			out_index = ((size_t)x + (size_t)y * P.W) * 3;
+		}
+	}
+	const bool writes = alive;
+
+	V3 acc = mk(0.0, 0.0, 0.0);
+	if (!LIST && alive && !to_buffer) acc = ld3(out + out_index);
+	if (P.bounce_limit == 0u) { // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237): every sample is (0, 0, 0)
+		if (LIST && writes) out[out_index + 0] = 0.0, out[out_index + 1] = 0.0, out[out_index + 2] = 0.0;
+		return; // tile launches with bounce_limit 0 are not made at all (api.cpp): the frame is unchanged
+	}
+
+	const V3 cam_pos = ld3(P.cam_pos);
+	Rng rng;
+	rng.init(0u, 0u);
+	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+	uint32_t depth = 1; // depth argument of the trace() call being evaluated
+	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
+	uint32_t path_len = 0;
+	// Every trip of the loop has two halves.  (B) each lane that needs a ray gets one — the bounce ray of the hit its last
+	// intersection found (`to_shade`), or the primary ray of the next sample when its path has ended (`need_sample`) — in ONE
+	// merged instruction stream (next_ray).  (A) every lane that has a ray intersects it with the scene and classifies the hit.
+	bool need_sample = alive || to_buffer; // no path yet
+	bool has_ray = false, to_shade = false;
+	// the hit a lane will shade on its next trip: object and distance (the hit point and the material are re-derived from them),
+	// and the surface normal — in registers, or, in the grid kernel (which runs at its register limit), parked in the wave's
+	// walk scratch: that LDS is only in use during a walk, i.e. never between the end of (A) and the next (B)
+	int hit_obj = -1;
+	double hit_t = 0.0;
+	V3 hit_normal = mk(0.0, 0.0, 1.0);
+	double *parked = GRID ? reinterpret_cast<double *>(wave_lds) + lane : nullptr; // normal at [0], [64], [128]; distance at [192]
+	int32_t *parked_obj = GRID ? reinterpret_cast<int32_t *>(wave_lds + 256u * sizeof(double)) + lane : nullptr;
+	static_assert(!GRID || sizeof(WalkScratch) >= 256u * sizeof(double) + 64u * sizeof(int32_t), "the walk scratch holds a wave's parked hits");
+	// grid scenes: a ray's closest plane/sphere hit while the lane waits for the walk that settles the grids (see intersect_simple)
+	bool new_ray = false, waiting = false;
+	uint32_t trips_since_walk = 0; // wave-uniform
+	double part_t = kFMax;
+	int part_obj = -1;
+	uint32_t part_sub = 0;
+
+	// Wave-uniform main loop: all 64 lanes stay in it until every lane has finished its samples, so that finished
+	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated.
+	for (;;) {
+		// ---------------- (B) hand out samples, then rays
+		bool prim = false;
+		if constexpr (to_buffer) {
+			// the next pool items go to the lanes whose path has ended
+			const unsigned long long idle = __ballot(need_sample);
+			if (idle != 0ull && next_item < pool_items) {
+				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+				next_item += (uint32_t)__popcll(idle);
+				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) { // slots outside a ragged tile are skipped
+					item = k, prim = true;
+					x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
+					s = P.sample_begin + pool_first + (item >> 6);
+				}
+			}
+			alive = prim || has_ray || to_shade;
+			if (__ballot(alive) == 0ull) {
+				if (next_item >= pool_items) break;
+				continue; // a handout that fell entirely on slots outside the tile
+			}
+		} else {
+			if (need_sample) {
+				if (s != s_end) prim = true; // src/trace.rs:199 — primary ray of sample s
+				else alive = false;
+			}
+			if (__ballot(alive) == 0ull) break;
+		}
+		if (prim) {
+			need_sample = false;
+			rng.init(y * P.W + x, s);
+			depth = 1;
+			has_ray = true, new_ray = true;
+		}
+		bool lens_failed = false;
+		if (P.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
+			if (prim) {
+				T = mk(1.0, 1.0, 1.0);
+				lens_failed = !primary_ray_dof(P, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
+			}
+			prim = false;
+		}
+		NextRayShadeIn hit;
+		hit.normal = hit_normal, hit.frag = ro, hit.color = ro, hit.roughness = 0.0, hit.metal = 0.0;
+		if (to_shade) {
+			if constexpr (GRID) hit.normal = mk(parked[0], parked[64], parked[128]), hit_t = parked[192], hit_obj = parked_obj[0];
+			const DevObject &o = lobjs[hit_obj];
+			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
+			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
+		}
+		next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
+		bool cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
+		if (to_shade) {
+			depth++;
+			to_shade = false;
+			if (depth > P.bounce_limit) cut = true, has_ray = false;
+			else has_ray = true, new_ray = true;
+		}
+#if RMD_DIAG
+		if ((P.debug_flags & 8u) && P.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
+			const unsigned long long am = __ballot(alive), wm = __ballot(has_ray && !lens_failed);
+			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm));
+		}
+#endif
+		// ---------------- (A) src/trace.rs:239 — closest hit of every lane that has a ray
+		const bool want = has_ray && !lens_failed;
+		double t;
+		uint32_t sub;
+		int oi;
+		bool complete; // lanes whose closest hit is known on this trip
+		if constexpr (GRID) {
+			if (want && new_ray) {
+				waiting = intersect_simple(objs, P.n_objects, grids, true, ro, rd, part_t, part_obj);
+				part_sub = 0u, new_ray = false;
+			}
+			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
+			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
+			trips_since_walk++;
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= P.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
+				trips_since_walk = 0;
+				intersect_grids(objs, P.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, P.debug_flags, P.debug_counters);
+				waiting = false;
+			}
+			complete = want && !waiting;
+			t = part_t, oi = part_obj, sub = part_sub;
+		} else {
+			oi = scene_intersect_wave<false>(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
+			complete = want;
+		}
+		bool terminal = lens_failed || cut;
+		V3 L = mk(0.0, 0.0, 0.0);
+		if (complete) {
+			if (LIST && path_obj) {
+				size_t pi = (size_t)list_idx * (RMD_PATH_STRIDE) + path_len;
+				path_obj[pi] = oi;
+				path_sub[pi] = oi >= 0 ? sub : 0u;
+				path_len++;
+			}
+			if (oi < 0) {
+				terminal = true; // :242 miss -> radiance 0
+			} else {
+				const DevObject &o = lobjs[oi];
+				const V3 frag = ro + rd * t; // :246
+				if (o.material_kind == 2u) {
+					L = ld3(o.color); // :250-252 Emission
+					terminal = true;
+				} else {
+					V3 normal;
+					if (o.geometry_kind == 0u) normal = ld3(o.normal);                        // plane.rs:28-32
+					else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin)); // sphere.rs:31-35
+					else if constexpr (GRID) {
+						const DevGrid &g = grids[o.grid_index];
+						normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, as_global(g.tri_aux) + (size_t)sub * 4, frag); // acc_grid.rs:85-87
+					} else {
+						normal = mk(0.0, 0.0, 0.0); // unreachable: a scene with grid objects runs the GRID instantiation
+					}
+					// At the bounce limit the recursive call returns 0 at once (:235-237) and this depth's result is its weight times
+					// that zero (:281-282 / :315-318): exactly zero whenever the weight is finite, so the shading is not evaluated.
+					// A weight is non-finite only through a non-finite input — the Heron normal of a degenerate hit, a hit point
+					// at infinity — (then the reference's sample is NaN, and so is this one: the lane shades and multiplies by zero on
+					// its next trip), or through r1 = 0 exactly in the diffuse pdf (probability 2^-53 per path; there the reference
+					// returns NaN and this kernel 0).
+					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
+					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
+					if (depth == P.bounce_limit && finite_inputs) {
+						terminal = true; // L = 0
+					} else {
+						if constexpr (GRID) parked[0] = normal.x, parked[64] = normal.y, parked[128] = normal.z, parked[192] = t, parked_obj[0] = oi;
+						else hit_normal = normal, hit_obj = oi, hit_t = t;
+						to_shade = true;
+					}
+				}
+			}
+			has_ray = false;
+		}
+		if (terminal) {
+			L = hadamard(T, L);
+			if constexpr (to_buffer) {
+				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
+				// sample's store travels alone, and a 24-byte store that straddles sectors was costing 2.7x its size in L2 write-backs
+				double *dst = P.sample_buf + (((size_t)wt * P.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
+				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+			} else {
+				acc = acc + L; // src/trace.rs:203
+				s++;
+			}
+			has_ray = false;
+			need_sample = true;
+		}
+	}
+
+	if (writes && !to_buffer) {
+		out[out_index + 0] = acc.x;
+		out[out_index + 1] = acc.y;
+		out[out_index + 2] = acc.z;
+	}
+}
+
+template <int MODE, bool GRID>
+inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
+                                uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub) {
+	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total);
+	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, wpw);
+	if (lds > 64u * 1024u) { // above the default dynamic-LDS limit: opt in on the current device (cheap, and correct per device)
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                   (int)kLdsBudgetBytes);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL((render_kernel<MODE, GRID>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
+	                   path_obj, path_sub);
+	return hipGetLastError();
+}
+
+
+} // namespace rmd

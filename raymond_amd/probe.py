@@ -1,5 +1,6 @@
 """Python wrappers of the diagnostic probes (include/raymond_hip_probe.h) for the parity tests."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -34,15 +35,23 @@ PATH_STRIDE = 17
 _ready = False
 
 
+PROBE_LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libraymond_hip_probe.so")  # beside the product library it links against
+_probe_lib = None
+
+
 def _L():
-    global _ready
-    L = _lib.load()
+    """libraymond_hip_probe.so: test infrastructure, a library of its own (the product library exports no probe)."""
+    global _ready, _probe_lib
     if not _ready:
+        _lib.load()  # the product library first: the probes call into it
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise ImportError("raymond_amd.probe: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'`" % PROBE_LIB_PATH)
+        _probe_lib = C.CDLL(PROBE_LIB_PATH)
         for name, args in _SIGS.items():
-            fn = getattr(L, name)
+            fn = getattr(_probe_lib, name)
             fn.restype, fn.argtypes = C.c_int32, args
         _ready = True
-    return L
+    return _probe_lib
 
 
 def _p(a):

@@ -12,25 +12,32 @@ import pytest
 from raymond_amd import abi, lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("raymond_hip.h", "raymond_hip_probe.h")]
+def declared_functions(header):
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(rmd_[a-z0-9_]+)\s*\(", text)))
 
 
-def declared_functions():
-    names = set()
-    for h in HEADERS:
-        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        names |= set(re.findall(r"\b(rmd_[a-z0-9_]+)\s*\(", text))
-    return sorted(names)
+def exported_functions(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return set(re.findall(r" T (rmd_[a-z0-9_]+)", out)), out
 
 
 def test_every_declared_symbol_is_exported(product_lib):
-    names = declared_functions()
-    assert len(names) >= 40
-    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
-    exported = set(re.findall(r" T (rmd_[a-z0-9_]+)", out))
+    """include/raymond_hip.h <-> libraymond_hip.so (the product), include/raymond_hip_probe.h <-> libraymond_hip_probe.so (test
+    infrastructure): each library exports every function its header declares, and the product exports no probe."""
+    from raymond_amd import probe
+
+    names = declared_functions("raymond_hip.h")
+    assert len(names) >= 28
+    exported, out = exported_functions(lib.LIB_PATH)
     missing = [n for n in names if n not in exported]
-    assert not missing, "declared in include/*.h but not exported: %s" % missing
+    assert not missing, "declared in include/raymond_hip.h but not exported: %s" % missing
     assert set(lib.SIGNATURES) <= exported
+    assert not [n for n in exported if n.startswith("rmd_probe_")]
+    probes = declared_functions("raymond_hip_probe.h")
+    assert len(probes) >= 18 and all(n.startswith("rmd_probe_") for n in probes)
+    probe_exported, _ = exported_functions(probe.PROBE_LIB_PATH)
+    assert not [n for n in probes if n not in probe_exported] and set(probe._SIGS) <= probe_exported
     # the boundary is plain C: no C++-mangled rmd entry points, no torch types anywhere near it
     assert not re.search(r" T _Z\w*rmd_render", out)
     assert product_lib.rmd_abi_version() == abi.RMD_ABI_VERSION
