@@ -255,8 +255,8 @@ def main():
         if bps is None:
             bps = 24.0 / spp
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
-        # <MODE, GRID> as rocprofv3 prints it; a shard is rendered with split samples (MODE 1)
-        kname = "rmd::render_kernel<%s>" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else ("0, false" if world == 1 else "1, false"))
+        # <MODE, GRID> as rocprofv3 prints it: launches split every tile's samples over several waves (MODE 1) + the ordered sum
+        kname = "rmd::render_kernel<%s> + rmd::sum_kernel" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else "1, false")
         out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"]}
         traffic = load_traffic(name, spp) if world == 1 else None
         rl = {

@@ -397,27 +397,25 @@ rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *
 	return RMD_OK;
 }
 
-// A wave owns 64 pixels x its sample range, so a launch with few wave tiles (an N-way tile shard, a small frame) has
-// too few, too long waves to fill 256 CUs evenly.  Such launches split every tile's samples over K waves that store
-// per-sample radiance to an HBM scratch buffer; sum_kernel then adds them in sample order — bit-identical to the
-// unsplit launch (tests/test_gpu_parity.py::test_sample_split_is_bit_exact).  RMD_SAMPLE_SPLIT=K forces K.
+// A wave owns 64 pixels x its sample range.  Splitting every tile's samples over K waves that store per-sample radiance to an HBM
+// scratch buffer — sum_kernel then adds them in sample order, bit-identical to the unsplit launch
+// (tests/test_gpu_parity.py::test_sample_split_is_bit_exact) — buys two things: enough waves to fill 256 CUs evenly when wave tiles
+// are few (an N-way shard) or very uneven (a mesh), and lanes that draw (pixel, sample) items from the wave's pool instead of
+// idling until the tile's longest pixel is done.  Measured optimum (tools/split_sweep.py, shares of 1, 1/2, 1/4 and 1/8 of the
+// 1080p frame): about 28 waves per resident wave slot for the spheres kernel (full frame K = 4: 120.2 vs 121.8 ms unsplit; half
+// frame K = 8: 60.9 vs 65.5) and about 24 for the mesh kernel (full frame K = 4: 117.3 vs 120.1 with K = 2), as long as a wave keeps
+// at least 8 samples.  RMD_TUNE_SAMPLE_SPLIT forces K.
 static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_wave_tiles, uint32_t sample_count) {
 	uint32_t k = 1;
 	if (ctx->tunable[RMD_TUNE_SAMPLE_SPLIT] > 0) {
 		k = (uint32_t)ctx->tunable[RMD_TUNE_SAMPLE_SPLIT];
+		if (k > sample_count / 4u) k = sample_count / 4u; // a forced split keeps >= 4 samples (256 pool items) per wave
 	} else if (n_wave_tiles != 0) {
-		if (has_grid) {
-			// mesh tiles cost ~10x wall tiles, so their waves form a long tail even on a full 1080p frame (measured: 2-way
-			// split 115.7 -> 105.2 ms; the scratch traffic, 48 B/sample, is noise next to ~2.3 us of walk per sample)
-			k = (8u * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
-			if (k < 2u) k = 2u;
-		} else if (n_wave_tiles < 3u * ctx->wave_slots) {
-			// uniform tiles: split only when wave tiles are scarce (an N-way shard); on a full frame the 48 B/sample of
-			// scratch traffic costs 3 % and buys nothing
-			k = (6u * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
-		}
+		const uint32_t waves_per_slot = has_grid ? 24u : 28u;
+		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
+		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
+		if (k > sample_count / 8u) k = sample_count / 8u;
 	}
-	if (k > sample_count / 4u) k = sample_count / 4u; // keep >= 4 samples (256 pool items) per wave
 	if (k > 64u) k = 64u;
 	while (k > 1u && (uint64_t)n_wave_tiles * k > 0x7FFFFFFFull) k--; // work items are indexed in 32 bits
 	return k < 2u ? 1u : k;
