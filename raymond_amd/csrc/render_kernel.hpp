@@ -169,8 +169,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	}
 
 	const V3 cam_pos = ld3(P.cam_pos);
-	Rng rng;
-	rng.init(0u, 0u);
+	uint32_t rng_block = 0; // index of the sample's next Philox block — all the RNG state a path carries (the key is its pixel and sample)
 	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
 	uint32_t depth = 1; // depth argument of the trace() call being evaluated
 	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
@@ -207,11 +206,8 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			if (idle != 0ull && next_item < pool_items) {
 				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				next_item += (uint32_t)__popcll(idle);
-				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) { // slots outside a ragged tile are skipped
+				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) // slots outside a ragged tile are skipped
 					item = k, prim = true;
-					x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
-					s = P.sample_begin + pool_first + (item >> 6);
-				}
 			}
 			alive = prim || has_ray || to_shade;
 			if (__ballot(alive) == 0ull) {
@@ -227,10 +223,18 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		}
 		if (prim) {
 			need_sample = false;
-			rng.init(y * P.W + x, s);
+			rng_block = 0;
 			depth = 1;
 			has_ray = true, new_ray = true;
 		}
+		// pixel and sample of the lane's path: in a split launch they are functions of the pool item (one integer of state per
+		// lane; kept as x, y, s they were spilled to scratch at every hand-out), otherwise the lane's own
+		if constexpr (to_buffer) {
+			x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
+			s = P.sample_begin + pool_first + (item >> 6);
+		}
+		Rng rng;
+		rng.pixel = y * P.W + x, rng.sample = s, rng.block = rng_block;
 		bool lens_failed = false;
 		if (P.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
 			if (prim) {
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
 		}
 		next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
+		rng_block = rng.block;
 		bool cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
 		if (to_shade) {
 			depth++;
