@@ -5,13 +5,14 @@
 
 A "step" is one full pass of the hot path over the workload: every pixel of the 1920x1080 frame receives all 500
 samples (rmd_render_tiles over this rank's share of the 32x32 host tiles, sample_begin 0, sample_count 500) and, for
-N > 1, the accumulated f64 framebuffer is summed onto rank 0 with one RCCL reduce.  The frame is a fixed amount of
+N > 1, rank 0 assembles the frame with ONE RCCL collective: a gather of the tiles each rank owns (default; 1/N of a
+frame per rank) or --assemble reduce, a sum of the full f64 framebuffers.  The frame is a fixed amount of
 work split over the ranks (tile i -> rank i mod N), so scaling is "strong".  Scene, camera and tile list are resident
 in HBM before the timed region; the timed region is bracketed by barrier + synchronize and the maximum over ranks
 is reported.
 
 The JSON line also carries
-  roofline      HBM roofline of the traversal (same kernel, GoldDragon-standin mesh, config C3 at reduced spp): the
+  roofline      HBM roofline of the traversal (same kernel, GoldDragon-standin mesh, config C3 at its 500 spp, one launch): the
                 spheres workload touches ~0.05 B/sample and is FP64-VALU bound, so its HBM fraction is reported
                 separately as roofline_c2 and is not the figure to optimise;
   cpu_baseline  the CPU oracle (reference-equivalent C++ restatement, kind "port") timed on this box's host cores
@@ -40,6 +41,9 @@ def parse():
     ap.add_argument("--roofline-spp", type=int, default=None, help="spp of the C3 roofline leg (default: the config's 500)")
     ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = calibrate to ~15 s)")
+    ap.add_argument("--assemble", default="gather", choices=["gather", "reduce"],
+                    help="N > 1: how rank 0 gets the frame - gather of the tiles each rank owns (1/N of a frame per rank) or "
+                         "reduce(sum) of the full frames; both bit-identical to the 1-GPU frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
     return ap.parse_args()
@@ -182,11 +186,16 @@ def main():
         fb = render.Framebuffer(ctx, W, H, device_ptr=fb_t.data_ptr())
         arr = (tile_array(share), len(share))
         kernel_ms = []
+        gather = None
+        if reduce and dist is not None and args.assemble == "gather":
+            gather = shard.OwnedTileGather(torch, W, H, tiles, rank, world, dev, root=0)
 
         def step():
             fb_t.zero_()
             render.render_tiles(ctx, ds, cam, st, arr, fb, 0, st.sample_count, sync=False)
-            if reduce and dist is not None:
+            if gather is not None:
+                gather(dist, fb_t, stage_host=(backend != "nccl"))
+            elif reduce and dist is not None:
                 if backend == "nccl":
                     shard.reduce_framebuffer(dist, fb_t, root=0)
                 else:  # rehearsal: stage through the host
@@ -242,7 +251,8 @@ def main():
         "config": {
             "workload": "%s: %s, %dx%d, %d spp, %d bounces, 32x32 host tiles round-robin over %d GPU(s)%s"
             % (name, scenes.CONFIGS[name][0], main_run["W"], main_run["H"], spp, main_run["st"].bounce_limit, world,
-               ", RCCL reduce(sum) of the f64 framebuffer to rank 0" if world > 1 else ""),
+               (", RCCL gather of each rank's own tiles to rank 0" if args.assemble == "gather" else
+                ", RCCL reduce(sum) of the f64 framebuffer to rank 0") if world > 1 else ""),
             "rng": "philox4x32-10 keyed (seed; pixel, sample, draw)",
             "seed": scenes.SEED,
         },

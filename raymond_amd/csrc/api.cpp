@@ -500,8 +500,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		RMD_HIP(ctx, hipMemcpyAsync(h, ctx->d_debug_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
 		RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		if (P.debug_flags & 16u)
-			std::fprintf(stderr, "[rmd stamps, cycles] init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
-			             h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
+			std::fprintf(stderr, "[rmd stamps, cycles] wave_total=%llu next_ray=%llu simple=%llu walk=%llu classify=%llu | walk: init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
+			             h[0], h[1], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
 		else
 			std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu tests=%llu chunks=%llu | main_iterations=%llu live_lanes=%llu lanes_with_ray=%llu shade_passes=%llu shaded_lanes=%llu\n",
 			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[14], h[13]);

@@ -206,6 +206,102 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 	}
 }
 
+// The stepping loop of a round for grids with one mask bit per cell, written out as one block of gfx950 assembly
+// (RMD_WALK_ASM_LOOP; dda_collect_candidates above is the same algorithm in C++ and serves coarser masks).  A SIMD issues at
+// most one vector and one scalar instruction per 4 cycles, from different waves, so the loop is as slow as the LONGER of
+// its two streams: the compiler's rendering of the C++ loop has 26 vector + 20 scalar instructions per step (32 + 22 when
+// a candidate is recorded), this one 19 + 17 (22 + 18):
+//   * the lane's cell index is stored to its next candidate slot on EVERY step (an LDS store, neither stream) and the slot
+//     only advances when the cell turns out occupied — no copy of the index from before the step is kept;
+//   * the exit counters are kept minus one and decremented with v_sub_co: the borrow IS "this axis left the grid"
+//     (acc_grid.rs:158,164,172,178) — no minimum of three, no compare; carry-outs of lanes outside exec are written as 0,
+//     like a compare's, so the three axis blocks' borrows are simply OR-ed;
+//   * the step budget and the candidates left count down the same way, their borrows join the round's stop mask;
+//   * the set of lanes still stepping lives in one scalar pair from which exec is re-made, instead of save / restore pairs.
+// Executed by the lanes that are walking (divergent call); exec is saved on entry and restored on exit; the scalar temporaries
+// are fixed registers named in the clobber list (an asm statement takes at most 30 operands).  Every step uses up one of the
+// lane's exit counters, so a lane leaves the loop after at most res.x + res.y + res.z steps.  Arithmetic on t_max, the axis
+// choice, the index, the end-of-array test and the order of the recorded candidates are those of RMD_DDA_ITERATION, bit for bit.
+#ifndef RMD_WALK_ASM_LOOP
+#define RMD_WALK_ASM_LOOP 1
+#endif
+RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bit, uint32_t idx_limit, uint32_t cand_base, bool &walking, uint32_t &n_cand,
+                                             uint32_t &idx, uint32_t &remx, uint32_t &remy, uint32_t &remz, double &tmx, double &tmy, double &tmz, double tdx,
+                                             double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz) {
+	uint32_t caddr = cand_base, bit, word, budget, cleft;
+	asm volatile(
+	    "s_mov_b64 s[86:87], exec\n\t"                      /* entry exec */
+	    "s_mov_b64 s[94:95], exec\n\t"                      /* lanes still stepping in this round */
+	    "s_mov_b64 s[88:89], 0\n\t"                         /* lanes whose walk has ended */
+	    "v_mov_b32 %[budget], 0x7ffffffe\n\t"               /* unlimited until the first candidate */
+	    "v_mov_b32 %[cleft], %[ncand1]\n\t"
+	    "v_add_u32 %[rx], -1, %[rx]\n\t"
+	    "v_add_u32 %[ry], -1, %[ry]\n\t"
+	    "v_add_u32 %[rz], -1, %[rz]\n\t"
+	    "s_waitcnt lgkmcnt(0)\n"
+	    "Lrmd_dda_loop%=:\n\t"
+	    "v_min_u32 %[bit], %[pad], %[idx]\n\t"
+	    "v_lshrrev_b32 %[word], 5, %[bit]\n\t"
+	    "v_lshl_add_u32 %[word], %[word], 2, %[mbase]\n\t"
+	    "ds_read_b32 %[word], %[word]\n\t"
+	    "ds_write_b32 %[caddr], %[idx]\n\t"                 /* the cell the lane stands on, into its next candidate slot */
+	    "v_cmp_lt_f64 s[90:91], %[tmx], %[tmy]\n\t"
+	    "v_cmp_lt_f64 s[92:93], %[tmx], %[tmz]\n\t"
+	    "v_cmp_lt_f64 vcc, %[tmy], %[tmz]\n\t"
+	    "s_and_b64 s[92:93], s[90:91], s[92:93]\n\t"        /* x:  tmx < tmy && tmx < tmz */
+	    "s_andn2_b64 vcc, vcc, s[90:91]\n\t"                /* y: !(tmx < tmy) && tmy < tmz */
+	    "s_mov_b64 exec, s[92:93]\n\t"
+	    "v_add_f64 %[tmx], %[tmx], %[tdx]\n\t"
+	    "v_sub_co_u32_e64 %[rx], s[90:91], %[rx], 1\n\t"    /* borrow: the x counter was 0 = the ray leaves the grid (0 for lanes outside exec) */
+	    "v_add_u32 %[idx], %[idx], %[dix]\n\t"
+	    "s_mov_b64 exec, vcc\n\t"
+	    "v_add_f64 %[tmy], %[tmy], %[tdy]\n\t"
+	    "v_sub_co_u32_e64 %[ry], s[96:97], %[ry], 1\n\t"
+	    "v_add_u32 %[idx], %[idx], %[diy]\n\t"
+	    "s_or_b64 vcc, vcc, s[92:93]\n\t"
+	    "s_andn2_b64 exec, s[94:95], vcc\n\t"               /* z: the rest */
+	    "s_or_b64 s[90:91], s[90:91], s[96:97]\n\t"
+	    "v_add_f64 %[tmz], %[tmz], %[tdz]\n\t"
+	    "v_sub_co_u32_e64 %[rz], s[96:97], %[rz], 1\n\t"
+	    "v_add_u32 %[idx], %[idx], %[diz]\n\t"
+	    "s_mov_b64 exec, s[94:95]\n\t"
+	    "s_or_b64 s[90:91], s[90:91], s[96:97]\n\t"
+	    "v_cmp_le_u32_e64 s[96:97], %[limit], %[idx]\n\t"   /* the next cell is past the cell array (:129-131): None */
+	    "v_subrev_co_u32_e32 %[budget], vcc, 1, %[budget]\n\t" /* borrow: the look-ahead budget is used up */
+	    "s_or_b64 s[90:91], s[90:91], s[96:97]\n\t"         /* lanes whose walk ended on this step */
+	    "s_or_b64 s[88:89], s[88:89], s[90:91]\n\t"
+	    "s_or_b64 s[90:91], s[90:91], vcc\n\t"              /* the round's stop mask */
+	    "s_waitcnt lgkmcnt(1)\n\t"                          /* the mask word (the store behind it may still be in flight) */
+	    "v_bfe_u32 %[bit], %[word], %[bit], 1\n\t"          /* bit position modulo 32 */
+	    "v_cmp_ne_u32_e32 vcc, 0, %[bit]\n\t"
+	    "s_and_b64 exec, s[94:95], vcc\n\t"
+	    "s_cbranch_execz Lrmd_dda_nocand%=\n\t"
+	    "v_add_u32 %[caddr], 0x100, %[caddr]\n\t"           /* the stored index stays: next slot */
+	    "v_min_u32 %[budget], %[look1], %[budget]\n\t"
+	    "v_subrev_co_u32_e32 %[cleft], vcc, 1, %[cleft]\n\t" /* borrow: that was the lane's last slot */
+	    "s_or_b64 s[90:91], s[90:91], vcc\n"
+	    "Lrmd_dda_nocand%=:\n\t"
+	    "s_andn2_b64 s[94:95], s[94:95], s[90:91]\n\t"
+	    "s_mov_b64 exec, s[94:95]\n\t"
+	    "s_cbranch_execnz Lrmd_dda_loop%=\n\t"
+	    "s_mov_b64 exec, s[86:87]\n\t"
+	    "v_mov_b32 %[bit], 0\n\t"
+	    "s_and_b64 exec, s[88:89], s[86:87]\n\t"
+	    "v_mov_b32 %[bit], 1\n\t"                           /* the walk of these lanes is over */
+	    "s_mov_b64 exec, s[86:87]\n\t"
+	    "v_add_u32 %[rx], 1, %[rx]\n\t"
+	    "v_add_u32 %[ry], 1, %[ry]\n\t"
+	    "v_add_u32 %[rz], 1, %[rz]\n\t"
+	    "s_waitcnt lgkmcnt(0)"
+	    : [tmx] "+v"(tmx), [tmy] "+v"(tmy), [tmz] "+v"(tmz), [idx] "+v"(idx), [rx] "+v"(remx), [ry] "+v"(remy), [rz] "+v"(remz), [caddr] "+v"(caddr),
+	      [bit] "=&v"(bit), [word] "=&v"(word), [budget] "=&v"(budget), [cleft] "=&v"(cleft)
+	    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [dix] "v"(dix), [diy] "v"(diy), [diz] "v"(diz), [pad] "s"(mask_pad_bit), [mbase] "s"(mask_base),
+	      [limit] "s"(idx_limit), [ncand1] "n"(RMD_WALK_CANDIDATES - 1), [look1] "n"(RMD_WALK_LOOKAHEAD - 1)
+	    : "vcc", "scc", "memory", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
+	n_cand = (caddr - cand_base) >> 8;
+	walking = bit == 0u;
+}
+
 // Must be called by all 64 lanes of the wave in uniform control flow; `want` selects the lanes that have a ray.
 // lds_mask: occupancy bits of this grid in LDS (bit i covers cells [i << shift, (i+1) << shift)).
 // scr: this wave's scratch in LDS.
@@ -240,8 +336,9 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	// every cell inside the grid has an index inside the cell array when res.z <= res.y (the Q5 index x + res.x*(y + z*res.z) of a
 	// cell with y < res.y, z < res.z is then below res.x*res.y*res.z); with one mask bit per cell as well, the stepping loops need
 	// neither the mask shift nor the index test — unless a lane starts from a cell outside the grid (Q6)
-	const bool lean_grid = mask_shift == 0u && g.res[2] <= g.res[1];
-	bool walking = false, start_outside = false;
+	[[maybe_unused]] const bool lean_grid = mask_shift == 0u && g.res[2] <= g.res[1];
+	bool walking = false;
+	[[maybe_unused]] bool start_outside = false;
 	int32_t dix = 0, diy = 0, diz = 0;
 	uint32_t idx = 0, remx = 1, remy = 1, remz = 1;
 	double tmx = 0.0, tmy = 0.0, tmz = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
@@ -314,8 +411,16 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		// LEAN (uniform per round): the mask has one bit per cell and every cell inside the grid has an index inside the cell
 		// array (res.z <= res.y), so neither the shift nor the index test is needed as long as no lane of the wave started
 		// from a cell outside the grid (Q6).
+#if RMD_WALK_ASM_LOOP
+		if (mask_shift == 0u) { // one mask bit per cell (uniform): the assembly loop
+			if (walking)
+				dda_collect_candidates_asm((uint32_t)(uintptr_t)lds_mask, mask_pad_bit, idx_limit, (uint32_t)(uintptr_t)&scr.first[lane], walking, n_cand, idx,
+				                           remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+		}
+#else
 		const bool lean = lean_grid && __ballot(walking && start_outside) == 0ull;
 		if (lean) dda_collect_candidates<true>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+#endif
 		else dda_collect_candidates<false>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
 		RMD_STAMP(1)
 		if (__ballot(n_cand != 0u) == 0ull) {

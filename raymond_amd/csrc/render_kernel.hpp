@@ -197,7 +197,22 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 
 	// Wave-uniform main loop: all 64 lanes stay in it until every lane has finished its samples, so that finished
 	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated.
+#if RMD_DIAG
+	const bool tstamp = (P.debug_flags & 16u) && P.debug_counters; // where a wave's time goes, trip by trip (perturbs the overlap of loads)
+	unsigned long long tt_prev = tstamp ? __builtin_amdgcn_s_memtime() : 0ull, tt_b = 0, tt_simple = 0, tt_walk = 0, tt_class = 0;
+	const unsigned long long tt_begin = tt_prev;
+#define RMD_TSTAMP(acc)                                         \
+	if (tstamp) {                                               \
+		__builtin_amdgcn_s_waitcnt(0);                          \
+		unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+		acc += now_ - tt_prev;                                  \
+		tt_prev = now_;                                         \
+	}
+#else
+#define RMD_TSTAMP(acc)
+#endif
 	for (;;) {
+		RMD_TSTAMP(tt_class)
 		// ---------------- (B) hand out samples, then rays
 		bool prim = false;
 		if constexpr (to_buffer) {
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm));
 		}
 #endif
+		RMD_TSTAMP(tt_b)
 		// ---------------- (A) src/trace.rs:239 — closest hit of every lane that has a ray
 		const bool want = has_ray && !lens_failed;
 		double t;
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 				waiting = intersect_simple(objs, P.n_objects, grids, true, ro, rd, part_t, part_obj);
 				part_sub = 0u, new_ray = false;
 			}
+			RMD_TSTAMP(tt_simple)
 			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
 			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
 			trips_since_walk++;
@@ -285,6 +302,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 				intersect_grids(objs, P.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, P.debug_flags, P.debug_counters);
 				waiting = false;
 			}
+			RMD_TSTAMP(tt_walk)
 			complete = want && !waiting;
 			t = part_t, oi = part_obj, sub = part_sub;
 		} else {
@@ -353,6 +371,13 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		}
 	}
 
+#if RMD_DIAG
+	if (tstamp && lane == 0) {
+		atomicAdd(&P.debug_counters[0], __builtin_amdgcn_s_memtime() - tt_begin), atomicAdd(&P.debug_counters[1], tt_b);
+		atomicAdd(&P.debug_counters[2], tt_simple), atomicAdd(&P.debug_counters[3], tt_walk), atomicAdd(&P.debug_counters[4], tt_class);
+	}
+#endif
+#undef RMD_TSTAMP
 	if (writes && !to_buffer) {
 		out[out_index + 0] = acc.x;
 		out[out_index + 1] = acc.y;

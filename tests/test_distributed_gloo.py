@@ -1,5 +1,6 @@
 """N > 1 host logic on CPU: two gloo ranks shard the tiles (raymond_amd.shard), render their share into zeroed
-full-size framebuffers and reduce(sum) to rank 0 — which must equal the single-process image bit for bit
+full-size framebuffers and assemble them on rank 0 (reduce(sum) of the frames, or a gather of the tiles each rank
+owns) — which must equal the single-process image bit for bit
 (SURVEY.md §8e).  The renderer here is the CPU oracle (this test checks the sharding/reduce logic, which is what
 bench.py --gpus N runs around rmd_render_tiles; the GPU equivalent is test_tile_shards_sum_to_the_full_image)."""
 import os
@@ -20,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, assemble="reduce"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -41,7 +42,12 @@ def _worker(rank, world, port, out_path):
         fb = torch.from_numpy(osc.render_tiles(cam, st, mine, threads=2))
         covered = torch.tensor([float(shard.shard_samples(mine))], dtype=torch.float64)
         dist.barrier()
-        shard.reduce_framebuffer(dist, fb, root=0)
+        if assemble == "gather":
+            g = shard.OwnedTileGather(torch, 160, 96, tiles, rank, world, "cpu", root=0)
+            assert g.pack_rows == max(shard.shard_samples(shard.shard_tiles(tiles, r, world)) for r in range(world))
+            g(dist, fb)
+        else:
+            shard.reduce_framebuffer(dist, fb, root=0)
         dist.all_reduce(covered)
         assert int(covered.item()) == 160 * 96  # the shards partition the frame
         if rank == 0:
@@ -51,8 +57,8 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_render_plus_reduce_equals_single_process(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,assemble", [(2, "reduce"), (3, "reduce"), (2, "gather"), (3, "gather")])
+def test_sharded_render_plus_reduce_equals_single_process(oracle, tmp_path, world, assemble):
     import multiprocessing
 
     from raymond_amd import scenes, shard
@@ -63,7 +69,7 @@ def test_sharded_render_plus_reduce_equals_single_process(oracle, tmp_path, worl
     # in the same session would otherwise run libraymond_hip.so's RCCL path next to torch's bundled ROCm libraries
     mp = multiprocessing.get_context("spawn")
     port = _free_port()
-    procs = [mp.Process(target=_worker, args=(rank, world, port, out_path)) for rank in range(world)]
+    procs = [mp.Process(target=_worker, args=(rank, world, port, out_path, assemble)) for rank in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -94,3 +100,33 @@ def test_shard_rejects_bad_rank():
 
     with pytest.raises(ValueError):
         shard.shard_tiles([(0, 0, 1, 1)], 2, 2)
+
+
+def test_owned_tile_gather_indices():
+    """The packs partition the frame: every pixel row is owned by exactly one rank; the padding of smaller shares is
+    never unpacked; a tile list that leaves pixels out leaves them untouched on the root."""
+    import torch
+
+    from raymond_amd import shard
+    from raymond_amd.scene import generate_tiles
+
+    W, H = 70, 50
+    tiles = generate_tiles(W, H, (32, 32))  # 6 tiles of four different sizes
+    for world in (1, 2, 4, 7):  # 7 > 6 tiles: one rank owns nothing
+        rows = [shard.tile_pixel_rows(shard.shard_tiles(tiles, r, world), W) for r in range(world)]
+        allrows = np.sort(np.concatenate(rows))
+        assert np.array_equal(allrows, np.arange(W * H))
+        # single-process emulation of the collective: rank r's frame holds r+1 on its own pixels
+        g = [shard.OwnedTileGather(torch, W, H, tiles, r, world, "cpu", root=0) for r in range(world)]
+        frames = []
+        for r in range(world):
+            f = torch.zeros(W * H * 3, dtype=torch.float64)
+            f.view(-1, 3)[torch.from_numpy(rows[r])] = float(r + 1)
+            frames.append(f)
+        for r in range(world):
+            g[0].recv[r].copy_(g[r].pack(frames[r]))
+        out = g[0].unpack(frames[0]).view(-1, 3)
+        for r in range(world):
+            assert bool((out[torch.from_numpy(rows[r])] == float(r + 1)).all())
+    # x, y of a row: x + y * W
+    assert shard.tile_pixel_rows([(64, 32, 6, 18)], W)[:7].tolist() == [64 + 32 * W + i for i in range(6)] + [64 + 33 * W]

@@ -143,8 +143,9 @@ def test_gpu_grid_build_is_byte_identical_to_the_host_builder(gpu_ctx, oracle):
 
 
 def test_bench_contract_and_two_rank_rehearsal(gpu_ctx):
-    """bench.py prints ONE JSON line with the driver's keys; a 2-rank run (rehearsal mode: both ranks on this GPU, reduce
-    over gloo — RCCL refuses two ranks on one device) reduces to the same frame as the 1-rank run, bit for bit."""
+    """bench.py prints ONE JSON line with the driver's keys; a 2-rank run (rehearsal mode: both ranks on this GPU, the
+    collective over gloo — RCCL refuses two ranks on one device) assembles the same frame as the 1-rank run, bit for bit, by
+    either route (gather of owned tiles, reduce of full frames)."""
     import json
     import os
     import subprocess
@@ -168,4 +169,11 @@ def test_bench_contract_and_two_rank_rehearsal(gpu_ctx):
     assert two.returncode == 0, two.stderr[-2000:]
     b = json.loads([l for l in two.stdout.split("\n") if l.startswith("{")][0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong"
-    assert b["kernel"]["checksum"] == a["kernel"]["checksum"]  # every pixel is non-zero on exactly one rank
+    assert b["kernel"]["checksum"] == a["kernel"]["checksum"]  # default: gather of the tiles each rank owns
+    assert "gather" in b["config"]["workload"]
+    red = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29578", os.path.join(root, "bench.py"), "--gpus", "2", "--assemble", "reduce"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert red.returncode == 0, red.stderr[-2000:]
+    c = json.loads([l for l in red.stdout.split("\n") if l.startswith("{")][0])
+    assert c["kernel"]["checksum"] == a["kernel"]["checksum"]  # every pixel is non-zero on exactly one rank
