@@ -486,7 +486,10 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				}
 			}
 			RMD_STAMP(3)
-			for (uint32_t base = 0; base < total; base += 64u) {
+			// Owner search of one chunk: which (lane, candidate) pair test number base + lane belongs to, and its triangle record.
+			// It runs ONE CHUNK AHEAD of the tests (RMD_WALK_SEARCH_AHEAD): a chunk's record loads are issued first, then the
+			// rays are fetched and the next chunk is searched while the records are on their way.
+			auto search = [&](uint32_t base, uint32_t &own, uint32_t &rec_index) {
 				const uint32_t w = base + lane;
 				scr.marker[lane] = 0u;
 				if (my_tests != 0u && my_begin < base + 64u && my_end > base) scr.marker[umax(my_begin, base) - base] = lane + 1u;
@@ -494,9 +497,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 				const uint32_t owner_lane = wave_scan_max(scr.marker[lane]) - 1u; // position 0 is always marked
-				bool h = false;
-				double t = 0.0;
-				uint32_t tri = 0, own = 0, rec_index = 0;
+				own = 0, rec_index = 0;
 				if (w < total) {
 					uint32_t slot = 0, slot_start = scr.start[owner_lane * kWalkCand];
 #pragma unroll
@@ -507,13 +508,24 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 					own = owner_lane | (slot << 8);
 					rec_index = scr.first[owner_lane * kWalkCand + slot] + (w - slot_start);
 				}
+				__builtin_amdgcn_wave_barrier(); // every lane has read the markers before the next search rewrites them
+			};
+			uint32_t own = 0, rec_index = 0;
+			search(0u, own, rec_index);
+			for (uint32_t base = 0; base < total; base += 64u) {
+				const uint32_t w = base + lane;
+				bool h = false;
+				double t = 0.0;
+				uint32_t tri = 0;
+				TriRecord r = {};
+				if (w < total) r = load_record(runs + (size_t)rec_index * 80u);
 				// the owner lane's ray, straight from its registers (every lane takes part in the permute)
 				const int src = (int)((own & 63u) << 2);
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
+				const uint32_t own_now = own;
+				if (base + 64u < total) search(base + 64u, own, rec_index);
 				if (w < total) {
-					const RMD_GLOBAL unsigned char *rec = runs + (size_t)rec_index * 80u;
-					const TriRecord r = load_record(rec);
 					tri = r.tri;
 					h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t);
 				}
@@ -522,7 +534,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				while (hits) {
 					const int l = (int)__builtin_ctzll(hits);
 					hits &= hits - 1ull;
-					const uint32_t ol = readlane_u32(own, l);
+					const uint32_t ol = readlane_u32(own_now, l);
 					const double tl = readlane_f64(t, l);
 					const uint32_t tril = readlane_u32(tri, l);
 					const uint32_t slot = ol >> 8;
