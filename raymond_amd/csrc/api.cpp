@@ -66,7 +66,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_MASK_BUDGET] = env_int("RMD_MASK_BUDGET");
 		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
 		const char *mode = std::getenv("RMD_GRID_MODE");
-		ctx->tunable[RMD_TUNE_GRID_MODE] = !mode ? 0 : (std::strcmp(mode, "wavefront") == 0 || std::strcmp(mode, "1") == 0) ? 1 : (std::strcmp(mode, "cuqueue") == 0 || std::strcmp(mode, "2") == 0) ? 2 : 0;
+		ctx->tunable[RMD_TUNE_GRID_MODE] = !mode ? 0 : (std::strcmp(mode, "wavefront") == 0 || std::strcmp(mode, "1") == 0) ? 1 : (std::strcmp(mode, "cuqueue") == 0 || std::strcmp(mode, "2") == 0) ? 2 : (std::strcmp(mode, "per-item") == 0 || std::strcmp(mode, "3") == 0) ? 3 : 0;
 		ctx->tunable[RMD_TUNE_CUQ_TRACERS] = env_int("RMD_CUQ_TRACERS");
 #if RMD_DIAG
 		ctx->debug_flags = (uint32_t)env_int("RMD_DEBUG"); // DIAG builds only: 1 | 2 are timing ablations that change results, 8 | 16 count events
@@ -191,6 +191,7 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->d_debug_counters) (void)hipFree(ctx->d_debug_counters);
 	if (ctx->d_wavefront_ws) (void)hipFree(ctx->d_wavefront_ws);
 	if (ctx->d_cuq_ws) (void)hipFree(ctx->d_cuq_ws);
+	if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -460,6 +461,10 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	// grid mode 2: persistent tracer / walker workgroups (cuqueue.hip); it writes per-sample output, i.e. it needs a split launch
 	const bool use_cuq = scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 2 && split > 1u && !(P.debug_flags & 16u);
 	if (use_cuq && !ctx->d_cuq_ws) RMD_HIP(ctx, hipMalloc(&ctx->d_cuq_ws, rmd::cuq_workspace_bytes()));
+	// grid scenes, default mode: the megakernel as persistent workgroups, one per CU, whose waves draw their work items from a counter
+	// (mode 3: one wave per work item, 4-wave workgroups — the form of round 1; 4.7 % slower on the benchmark mesh)
+	const bool persistent = scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 0 && !use_cuq;
+	if (persistent && !ctx->d_work_counter) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_work_counter, 256));
 	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes.  It may take a quarter of the
 	// device's HBM (72 GiB of 288: the whole C3 frame at 500 spp is 24.9 GB, one launch); what does not fit runs as several passes
 	uint32_t per_pass = P.sample_count;
@@ -490,7 +495,11 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			                                    (uint32_t)ctx->tunable[RMD_TUNE_CUQ_TRACERS]));
 			continue;
 		}
-		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev));
+		if (persistent) {
+			RMD_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));
+			Q.work_counter = ctx->d_work_counter;
+		}
+		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent ? ctx->n_cus : 0u));
 		if (settings->sample_count == 0) break;
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -512,7 +521,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value) {
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: null context");
 	if (key >= RMD_TUNE_COUNT || value < 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: unknown key or negative value");
-	if (key == RMD_TUNE_GRID_MODE && value > 2) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: grid mode is 0, 1 or 2");
+	if (key == RMD_TUNE_GRID_MODE && value > 3) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: grid mode is 0, 1, 2 or 3");
 	if (key == RMD_TUNE_CUQ_TRACERS && value > 15) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: 1..15 tracer waves");
 	ctx->tunable[key] = value;
 	return RMD_OK;

@@ -85,6 +85,7 @@ struct RenderParams {
 	double *sample_buf;        // [wave tile][sample - sample_begin][lane][3] f64, only when split_k > 1
 	uint32_t debug_flags;      // diagnostics (RMD_DEBUG env): 1 = skip triangle tests, 2 = skip grid walks (timing only, wrong results), 8 = count walk events
 	unsigned long long *debug_counters; // 16 counters, only touched when debug_flags & 8
+	uint32_t *work_counter;             // persistent launches: the next work item (zeroed by the host before the launch)
 };
 
 // List mode (probe): one lane per explicit (x, y, sample).

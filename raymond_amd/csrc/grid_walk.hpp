@@ -110,6 +110,9 @@ constexpr uint32_t kWalkCand = RMD_WALK_CANDIDATES;
 static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 // After its first candidate a lane keeps stepping at most this many cells looking for more (the non-empty cells of
 // one surface crossing are adjacent); further cells wait for the next round.
+#ifndef RMD_WALK_PREFETCH
+#define RMD_WALK_PREFETCH 0 // measured: 111.8 vs 108.8 ms on the 100-spp C3 launch (8 more spilled registers, one more load per chunk)
+#endif
 #ifndef RMD_WALK_ASM_STEP
 #define RMD_WALK_ASM_STEP 1
 #endif
@@ -525,11 +528,20 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				const uint32_t own_now = own;
 				if (base + 64u < total) search(base + 64u, own, rec_index);
+				uint32_t prefetched = 0;
+#if RMD_WALK_PREFETCH
+				// touch the next chunk's records (one word each: neighbouring tests read neighbouring records, so every line of a run is
+				// touched) so that its loads find them in the nearer caches.  Unconditional — lanes without a next test touch a record
+				// they already have — so that the wait for this chunk's records can leave exactly this one load outstanding; the word
+				// is only "used" after this chunk's tests.
+				prefetched = *reinterpret_cast<const RMD_GLOBAL uint32_t *>(runs + (size_t)rec_index * 80u);
+#endif
 				if (w < total) {
 					tri = r.tri;
 					h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t);
 				}
 				RMD_STAMP(5)
+				asm volatile("" ::"v"(prefetched));
 				unsigned long long hits = __ballot(h);
 				while (hits) {
 					const int l = (int)__builtin_ctzll(hits);

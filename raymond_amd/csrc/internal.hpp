@@ -37,6 +37,7 @@ struct rmd_context {
 	void *d_wavefront_ws = nullptr; // path state of the streaming mode (wavefront.hip)
 	size_t wavefront_ws_bytes = 0;
 	void *d_cuq_ws = nullptr; // work-item counter + error flag of grid mode 2 (cuqueue.hip)
+	uint32_t *d_work_counter = nullptr; // next work item of a persistent launch (render_kernel.hpp)
 	unsigned long long *d_debug_counters = nullptr; // walk diagnostics (DIAG builds, RMD_DEBUG=8|16)
 	// Tunables (include/raymond_hip.h: rmd_context_set_tunable).  Defaults come from the environment, read ONCE when the
 	// context is created; none of them changes a result.

@@ -74,13 +74,13 @@ uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total) {
 }
 
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
-                               const WaveTile *wave_tiles, double *accum) {
+                               const WaveTile *wave_tiles, double *accum, uint32_t n_cus) {
 	if (P.n_work == 0) return hipSuccess;
 	const uint32_t n_waves = P.n_work * (P.split_k > 1u ? P.split_k : 1u);
 	const bool buffered = P.split_k > 1u;
 	hipError_t e;
-	if (P.n_grids) e = buffered ? launch_render<kModeTilesBuffered, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
-	                            : launch_render<kModeTiles, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
+	if (P.n_grids) e = buffered ? launch_render<kModeTilesBuffered, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus)
+	                            : launch_render<kModeTiles, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus);
 	else e = buffered ? launch_render<kModeTilesBuffered, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
 	                  : launch_render<kModeTiles, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
 	if (e != hipSuccess || !buffered) return e;

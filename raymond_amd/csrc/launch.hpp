@@ -47,10 +47,13 @@ constexpr double kMaxRoughness = 512.0;
 #define RMD_GRID_WAVES 4
 #endif
 constexpr uint32_t kGridWavesPerWg = RMD_GRID_WAVES;
+// waves of a persistent workgroup (one per CU: all 16 wave slots that 128 registers per lane leave)
+constexpr uint32_t kPersistWavesPerWg = 16;
 size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg);
 uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total);
+// n_cus > 0 and P.work_counter set: grid scenes run as persistent workgroups (render_kernel.hpp)
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
-                               const WaveTile *wave_tiles, double *accum);
+                               const WaveTile *wave_tiles, double *accum, uint32_t n_cus = 0);
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub);
 // pixel += the per-sample radiance of a split launch, in sample order (kernels.hip: sum_kernel)

@@ -87,34 +87,16 @@ constexpr uint32_t kWalkMaxWait = RMD_WALK_MAX_WAIT;
 // (A template parameter rather than a launch parameter: the buffer mode then carries no accumulator and the direct mode no
 // buffer addressing — the grid kernel runs at its register limit.)
 enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
+// One wave's share of a launch: list mode — the 64 entries from `first`; tile modes — work item `first` = (wave tile, sample
+// sub-range).  Called by all 64 lanes of a wave in uniform control flow; lobjs / lds_masks / wave_lds are the workgroup's staged
+// object table and occupancy masks and this wave's scratch in LDS.
 template <int MODE, bool GRID>
-__global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_MINW : RMD_NOGRID_MINW) void render_kernel(RenderParams P, const DevObject *__restrict__ objs,
-                                                     const DevGrid *__restrict__ grids, const void *__restrict__ work,
-                                                     double *__restrict__ out, int32_t *__restrict__ path_obj,
-                                                     uint32_t *__restrict__ path_sub) {
+RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work,
+                         double *__restrict__ out, int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub, const DevObject *lobjs,
+                         const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first) {
 	constexpr bool LIST = MODE == kModeList;
-	extern __shared__ __align__(16) unsigned char smem[];
-	// LDS: [object table][grid occupancy masks][one walk scratch per wave]
-	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
-	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
-	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
-	                          (size_t)wave * wave_lds_bytes(P.n_grids);
+	const uint32_t lane = threadIdx.x & 63u;
 	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
-
-	// stage the object table and the occupancy masks: coalesced, once per workgroup
-	{
-		const double *src = reinterpret_cast<const double *>(objs);
-		double *dst = reinterpret_cast<double *>(lobjs);
-		for (uint32_t i = tid; i < P.n_objects * 16u; i += blockDim.x) dst[i] = src[i];
-		for (uint32_t gi = 0; gi < P.n_grids; gi++) {
-			const DevGrid &g = grids[gi];
-			if (g.mask_lds_word == 0xFFFFFFFFu) continue;
-			for (uint32_t i = tid; i < g.mask_n_words; i += blockDim.x) lmasks[g.mask_lds_word + i] = as_global(g.mask_words)[i];
-		}
-	}
-	__syncthreads(); // the only workgroup barrier: from here on every wave runs on its own
-	const uint32_t *lds_masks = P.mask_words_total ? lmasks : nullptr;
 
 	constexpr bool to_buffer = MODE == kModeTilesBuffered;
 	// Per-lane work.  LIST: one (x, y, sample) entry.  Tiles, direct mode: lane = pixel, samples s .. s_end-1 one after the
@@ -130,7 +112,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	uint32_t wt = 0, pool_first = 0, pool_items = 0, next_item = 0; // wave-uniform (buffered mode)
 	uint32_t item = 0;                                               // this lane's pool item (buffered mode)
 	if (LIST) {
-		list_idx = (blockIdx.x * waves_per_wg + wave) * 64u + lane;
+		list_idx = first + lane;
 		alive = list_idx < P.n_work;
 		ListWork w = reinterpret_cast<const ListWork *>(work)[alive ? list_idx : 0];
 		x = w.x, y = w.y, s = w.sample, s_end = w.sample + 1u;
@@ -139,7 +121,7 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 		// work item = (wave tile, sample sub-range): with split_k > 1 the samples of a tile are spread over split_k
 		// waves (neighbouring waves, same tile) that store every sample's radiance to the sample buffer; sum_kernel then
 		// adds them to the pixel in sample order, so the result is the same sequential sum as with one wave per tile
-		const uint32_t work_item = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
+		const uint32_t work_item = first;
 		const uint32_t split = to_buffer ? P.split_k : 1u;
 		wt = work_item / split;
 		const uint32_t part = work_item % split;
@@ -385,17 +367,75 @@ __global__ __launch_bounds__(GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_M
 	}
 }
 
+// PERSIST = false: one wave per work item, block b's waves take items b * waves .. ; PERSIST = true (tile modes of grid scenes):
+// as many 16-wave workgroups as the device has CUs, each staging the masks ONCE, whose waves draw work items from a launch-wide
+// counter (P.work_counter, zeroed by the host) until none is left — the masks cost one copy per CU instead of one per
+// 4-wave workgroup, which leaves each wave 8 KB of LDS, and no wave slot idles while the rest of a workgroup finishes.
+template <int MODE, bool GRID, bool PERSIST>
+__global__ __launch_bounds__(GRID ? 64 * (PERSIST ? kPersistWavesPerWg : kGridWavesPerWg) : 64, GRID ? RMD_GRID_MINW : RMD_NOGRID_MINW) void render_kernel(
+    RenderParams P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work, double *__restrict__ out,
+    int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub) {
+	extern __shared__ __align__(16) unsigned char smem[];
+	// LDS: [object table][grid occupancy masks][one walk scratch per wave]
+	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
+	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
+	const uint32_t tid = threadIdx.x, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
+	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
+	                          (size_t)wave * wave_lds_bytes(P.n_grids);
+	// stage the object table and the occupancy masks: coalesced, once per workgroup
+	{
+		const double *src = reinterpret_cast<const double *>(objs);
+		double *dst = reinterpret_cast<double *>(lobjs);
+		for (uint32_t i = tid; i < P.n_objects * 16u; i += blockDim.x) dst[i] = src[i];
+		for (uint32_t gi = 0; gi < P.n_grids; gi++) {
+			const DevGrid &g = grids[gi];
+			if (g.mask_lds_word == 0xFFFFFFFFu) continue;
+			for (uint32_t i = tid; i < g.mask_n_words; i += blockDim.x) lmasks[g.mask_lds_word + i] = as_global(g.mask_words)[i];
+		}
+	}
+	__syncthreads(); // the only workgroup barrier: from here on every wave runs on its own
+	const uint32_t *lds_masks = P.mask_words_total ? lmasks : nullptr;
+	if constexpr (PERSIST) {
+		static_assert(MODE != kModeList, "list launches are not persistent");
+		const uint32_t n_items = P.n_work * (MODE == kModeTilesBuffered ? P.split_k : 1u);
+		for (;;) {
+			uint32_t item = 0;
+			if ((tid & 63u) == 0u) item = atomicAdd(P.work_counter, 1u);
+			item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+			if (item >= n_items) break;
+			render_wave<MODE, GRID>(P, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
+		}
+	} else {
+		const uint32_t unit = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
+		render_wave<MODE, GRID>(P, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, MODE == kModeList ? unit * 64u : unit);
+	}
+}
+
+// n_cus > 0 (tile modes of grid scenes): the persistent form, one 16-wave workgroup per CU (fewer when there are fewer work items);
+// P.work_counter must point at a zeroed device word.
 template <int MODE, bool GRID>
 inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
-                                uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub) {
+                                uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub, uint32_t n_cus = 0) {
+	if constexpr (GRID && MODE != kModeList) {
+		if (n_cus != 0u && P.work_counter != nullptr && render_lds_bytes(P.n_objects, P.mask_words_total, kPersistWavesPerWg) <= kLdsBudgetBytes) {
+			const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, kPersistWavesPerWg);
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+			                                   (int)kLdsBudgetBytes);
+			if (e != hipSuccess) return e;
+			const uint32_t wgs = (n_waves + kPersistWavesPerWg - 1u) / kPersistWavesPerWg;
+			hipLaunchKernelGGL((render_kernel<MODE, GRID, true>), dim3(wgs < n_cus ? wgs : n_cus), dim3(64u * kPersistWavesPerWg), lds, stream, P, objs, grids,
+			                   work, out, path_obj, path_sub);
+			return hipGetLastError();
+		}
+	}
 	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total);
 	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, wpw);
 	if (lds > 64u * 1024u) { // above the default dynamic-LDS limit: opt in on the current device (cheap, and correct per device)
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                   (int)kLdsBudgetBytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((render_kernel<MODE, GRID>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
+	hipLaunchKernelGGL((render_kernel<MODE, GRID, false>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
 	                   path_obj, path_sub);
 	return hipGetLastError();
 }

@@ -727,14 +727,18 @@ def test_cu_queue_mode_is_bit_identical(gpu_ctx, small_mesh_scene, oracle):
         ds = render.DeviceScene(gpu_ctx, sc)
         fb = render.Framebuffer(gpu_ctx, W, H)
         out = {}
-        for mode in (0, 2):
+        # mode 0 = persistent workgroups drawing work items from a counter (the default), 3 = one wave per work item, 2 = CU queue;
+        # (mode, forced split): 0 = the library's choice (direct mode for these few samples), 3 = three waves per wave tile
+        for mode, split in ((0, 0), (2, 0), (3, 0), (0, 3), (3, 3)):
             gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, mode), gpu_ctx.set_tunable(abi.RMD_TUNE_CUQ_TRACERS, tracers)
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
             try:
                 fb.upload(base)
                 render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, begin, count)
-                out[mode] = fb.download()
+                out[(mode, split)] = fb.download()
             finally:
-                gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_CUQ_TRACERS, 0)
-        assert out[2].tobytes() == out[0].tobytes(), (W, H, tracers)
-        assert (out[0] != base).any()
+                gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_CUQ_TRACERS, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0)
+        for key, img in out.items():
+            assert img.tobytes() == out[(0, 0)].tobytes(), (W, H, tracers, key)
+        assert (out[(0, 0)] != base).any()
         fb.close(), ds.close()
