@@ -412,10 +412,14 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 		k = (uint32_t)ctx->tunable[RMD_TUNE_SAMPLE_SPLIT];
 		if (k > sample_count / 4u) k = sample_count / 4u; // a forced split keeps >= 4 samples (256 pool items) per wave
 	} else if (n_wave_tiles != 0) {
-		const uint32_t waves_per_slot = has_grid ? 24u : 28u;
+		// work items per wave slot.  Mesh scenes run as persistent workgroups whose waves draw items from a counter: about 64 items
+		// per slot level the tail (tools/split_sweep.py, full C3 frame: 512.8 ms at 32, 508.1 at 64 .. 128, 517.8 at 500), of at
+		// least 4 samples; the spheres kernel launches one wave per item: 28 per slot, at least 8 samples
+		const uint32_t waves_per_slot = has_grid ? 64u : 28u;
 		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
-		if (k > sample_count / 8u) k = sample_count / 8u;
+		const uint32_t min_samples = has_grid ? 4u : 8u;
+		if (k > sample_count / min_samples) k = sample_count / min_samples;
 	}
 	if (k > 64u) k = 64u;
 	while (k > 1u && (uint64_t)n_wave_tiles * k > 0x7FFFFFFFull) k--; // work items are indexed in 32 bits
