@@ -11,7 +11,8 @@
 namespace rmd {
 
 // LDS per wave: the cooperative-walk scratch, only when the scene has grids.
-__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) : 0; }
+// per-wave LDS of the grid kernel: the walk scratch and the 64 paths' throughput (3 doubles per lane)
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) : 0; }
 
 // Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
 // reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
@@ -154,7 +155,18 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 	uint32_t rng_block = 0; // index of the sample's next Philox block — all the RNG state a path carries (the key is its pixel and sample)
 	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
 	uint32_t depth = 1; // depth argument of the trace() call being evaluated
-	V3 T = mk(1.0, 1.0, 1.0); // throughput: product of the bounce weights of the path so far
+	// throughput: product of the bounce weights of the path so far.  It is read and written once per bounce and read when the path ends;
+	// the grid kernel (at its register limit: one component was living in scratch) keeps it in LDS behind the wave's walk scratch
+	V3 T_reg = mk(1.0, 1.0, 1.0);
+	[[maybe_unused]] double *T_lds = GRID ? reinterpret_cast<double *>(wave_lds + sizeof(WalkScratch)) + lane : nullptr;
+	auto load_T = [&]() -> V3 {
+		if constexpr (GRID) return mk(T_lds[0], T_lds[64], T_lds[128]);
+		else return T_reg;
+	};
+	auto store_T = [&](V3 v) {
+		if constexpr (GRID) T_lds[0] = v.x, T_lds[64] = v.y, T_lds[128] = v.z;
+		else T_reg = v;
+	};
 	uint32_t path_len = 0;
 	// Every trip of the loop has two halves.  (B) each lane that needs a ray gets one — the bounce ray of the hit its last
 	// intersection found (`to_shade`), or the primary ray of the next sample when its path has ended (`need_sample`) — in ONE
@@ -235,7 +247,7 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 		bool lens_failed = false;
 		if (P.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
 			if (prim) {
-				T = mk(1.0, 1.0, 1.0);
+				store_T(mk(1.0, 1.0, 1.0));
 				lens_failed = !primary_ray_dof(P, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
 			}
 			prim = false;
@@ -248,7 +260,14 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
 			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
 		}
-		next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
+		if constexpr (GRID) {
+			V3 T = mk(1.0, 1.0, 1.0);
+			if (to_shade) T = load_T();
+			next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
+			if (to_shade || prim) store_T(T);
+		} else {
+			next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
+		}
 		rng_block = rng.block;
 		bool cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
 		if (to_shade) {
@@ -338,7 +357,7 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 			has_ray = false;
 		}
 		if (terminal) {
-			L = hadamard(T, L);
+			L = hadamard(load_T(), L);
 			if constexpr (to_buffer) {
 				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
 				// sample's store travels alone, and a 24-byte store that straddles sectors was costing 2.7x its size in L2 write-backs
