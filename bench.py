@@ -266,7 +266,7 @@ def main():
             bps = 24.0 / spp
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
         # <MODE, GRID> as rocprofv3 prints it: launches split every tile's samples over several waves (MODE 1) + the ordered sum
-        kname = "rmd::render_kernel<%s> + rmd::sum_kernel" % ("1, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else "1, false")
+        kname = "rmd::render_kernel<%s> + rmd::sum_kernel" % ("1, true, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else "1, false, false")
         out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"]}
         traffic = load_traffic(name, spp) if world == 1 else None
         rl = {
@@ -297,12 +297,12 @@ def main():
             "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic,
             "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch" % rspp,
-            "kernel": "rmd::render_kernel<1, true> + rmd::sum_kernel", "avg_ms": round(avg_ms, 3), "launch_ms": [round(v, 3) for v in rr["kernel_ms"]],
+            "kernel": "rmd::render_kernel<1, true, true> + rmd::sum_kernel", "avg_ms": round(avg_ms, 3), "launch_ms": [round(v, 3) for v in rr["kernel_ms"]],
             "bytes_per_sample": round(bps, 2), "bytes_per_launch": bps * rr["samples_per_step"],
             "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
             "how": "achieved = algorithmic bytes per launch (8 B x cells visited + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
                    "oracle counters in tests/golden/work_counters.json, + 24 B/pixel) / mean launch duration from HIP events on the launch stream; "
-                   "profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true> + sum_kernel over the same launches",
+                   "profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true> (persistent workgroups) + sum_kernel over the same launches",
         }
         if traffic is not None:
             # L2<->fabric bytes per launch by PMC (upper bound on HBM bytes: Infinity-Cache hits are included)

@@ -117,7 +117,7 @@ static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 #define RMD_WALK_ASM_STEP 1
 #endif
 #ifndef RMD_WALK_LOOKAHEAD
-#define RMD_WALK_LOOKAHEAD 12
+#define RMD_WALK_LOOKAHEAD 16
 #endif
 constexpr uint32_t kWalkLookahead = RMD_WALK_LOOKAHEAD;
 

@@ -38,7 +38,7 @@ constexpr size_t kMaskBudgetBytes = 48u * 1024u;
 // doubles per entry of the per-sample scratch of split launches: r, g, b and one of padding = one 32-byte sector
 constexpr uint32_t kSampleStride = 4;
 // walk batching (kernels.hip): lanes of a wave that must be waiting for a grid walk before one is run
-constexpr uint32_t kWalkBatchDefault = 32;
+constexpr uint32_t kWalkBatchDefault = 40;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
 constexpr double kMaxRoughness = 512.0;
 // waves per workgroup of the grid instantiation (they share the LDS occupancy masks)

@@ -62,16 +62,16 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	return best;
 }
 
-// A walk is run when RenderParams::walk_batch lanes of the wave wait for one (launch.hpp: kWalkBatchDefault = 32, measured best
-// of 12..56 on the benchmark mesh),
+// A walk is run when RenderParams::walk_batch lanes of the wave wait for one (launch.hpp: kWalkBatchDefault = 40; with the persistent
+// workgroups 40 / 24 / 6 / look-ahead 16 measured 1.7 % faster on the benchmark mesh than round 1's 32 / 16 / 4 / 12),
 // ... or fewer than this many lanes could do anything else on this trip (a trip costs the same for 5 lanes as for 50)
 #ifndef RMD_WALK_MIN_RUNNABLE
-#define RMD_WALK_MIN_RUNNABLE 16
+#define RMD_WALK_MIN_RUNNABLE 24
 #endif
 constexpr uint32_t kWalkMinRunnable = RMD_WALK_MIN_RUNNABLE;
 // ... or this many trips have passed since the wave's last walk (scenes where few rays reach a grid: bounds the wait)
 #ifndef RMD_WALK_MAX_WAIT
-#define RMD_WALK_MAX_WAIT 4
+#define RMD_WALK_MAX_WAIT 6
 #endif
 constexpr uint32_t kWalkMaxWait = RMD_WALK_MAX_WAIT;
 
