@@ -88,6 +88,9 @@ constexpr uint32_t kWalkMaxWait = RMD_WALK_MAX_WAIT;
 // (A template parameter rather than a launch parameter: the buffer mode then carries no accumulator and the direct mode no
 // buffer addressing — the grid kernel runs at its register limit.)
 enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
+#ifndef RMD_TRIP_RELOAD
+#define RMD_TRIP_RELOAD 1
+#endif
 // One wave's share of a launch: list mode — the 64 entries from `first`; tile modes — work item `first` = (wave tile, sample
 // sub-range).  Called by all 64 lanes of a wave in uniform control flow; lobjs / lds_masks / wave_lds are the workgroup's staged
 // object table and occupancy masks and this wave's scratch in LDS.
@@ -206,6 +209,28 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 #define RMD_TSTAMP(acc)
 #endif
 	for (;;) {
+		// Grid kernel: the launch parameters a trip needs are read again from the kernel arguments (a few scalar loads per trip) instead
+		// of being carried in scalar registers across trips — it was spilling scalars into vector lanes all through the trip (168
+		// v_readlane / v_writelane at trip level, 41 now).  The empty asm keeps the compiler from hoisting the loads out of the loop.
+		auto trip_params = [&]() -> decltype(auto) {
+			if constexpr (GRID && RMD_TRIP_RELOAD) {
+				typedef const __attribute__((address_space(4))) unsigned long long *WordsInConstant;
+				// RenderParams is render_kernel's first argument: offset 0 of the kernel-argument segment
+				WordsInConstant src = (WordsInConstant)__builtin_amdgcn_kernarg_segment_ptr();
+				asm volatile("" : "+s"(src));
+				static_assert(sizeof(RenderParams) % 8 == 0, "copied in 8-byte words");
+				union {
+					RenderParams p;
+					unsigned long long w[sizeof(RenderParams) / 8];
+				} copy;
+#pragma unroll
+				for (unsigned i = 0; i < sizeof(RenderParams) / 8; i++) copy.w[i] = src[i];
+				return copy.p; // by value; only the fields a trip uses are loaded
+			} else {
+				return (P);
+			}
+		};
+		decltype(auto) Pt = trip_params();
 		RMD_TSTAMP(tt_class)
 		// ---------------- (B) hand out samples, then rays
 		bool prim = false;
@@ -240,15 +265,15 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 		// lane; kept as x, y, s they were spilled to scratch at every hand-out), otherwise the lane's own
 		if constexpr (to_buffer) {
 			x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
-			s = P.sample_begin + pool_first + (item >> 6);
+			s = Pt.sample_begin + pool_first + (item >> 6);
 		}
 		Rng rng;
-		rng.pixel = y * P.W + x, rng.sample = s, rng.block = rng_block;
+		rng.pixel = y * Pt.W + x, rng.sample = s, rng.block = rng_block;
 		bool lens_failed = false;
-		if (P.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
+		if (Pt.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
 			if (prim) {
 				store_T(mk(1.0, 1.0, 1.0));
-				lens_failed = !primary_ray_dof(P, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
+				lens_failed = !primary_ray_dof(Pt, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
 			}
 			prim = false;
 		}
@@ -263,23 +288,23 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 		if constexpr (GRID) {
 			V3 T = mk(1.0, 1.0, 1.0);
 			if (to_shade) T = load_T();
-			next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
+			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
 			if (to_shade || prim) store_T(T);
 		} else {
-			next_ray(P, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
+			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
 		}
 		rng_block = rng.block;
 		bool cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
 		if (to_shade) {
 			depth++;
 			to_shade = false;
-			if (depth > P.bounce_limit) cut = true, has_ray = false;
+			if (depth > Pt.bounce_limit) cut = true, has_ray = false;
 			else has_ray = true, new_ray = true;
 		}
 #if RMD_DIAG
-		if ((P.debug_flags & 8u) && P.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
+		if ((Pt.debug_flags & 8u) && Pt.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
 			const unsigned long long am = __ballot(alive), wm = __ballot(has_ray && !lens_failed);
-			if (lane == 0) atomicAdd(&P.debug_counters[10], 1ull), atomicAdd(&P.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&P.debug_counters[12], (unsigned long long)__popcll(wm));
+			if (lane == 0) atomicAdd(&Pt.debug_counters[10], 1ull), atomicAdd(&Pt.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&Pt.debug_counters[12], (unsigned long long)__popcll(wm));
 		}
 #endif
 		RMD_TSTAMP(tt_b)
@@ -291,23 +316,23 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 		bool complete; // lanes whose closest hit is known on this trip
 		if constexpr (GRID) {
 			if (want && new_ray) {
-				waiting = intersect_simple(objs, P.n_objects, grids, true, ro, rd, part_t, part_obj);
+				waiting = intersect_simple(objs, Pt.n_objects, grids, true, ro, rd, part_t, part_obj);
 				part_sub = 0u, new_ray = false;
 			}
 			RMD_TSTAMP(tt_simple)
 			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
 			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
 			trips_since_walk++;
-			if (wm != 0ull && ((uint32_t)__popcll(wm) >= P.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= Pt.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
 				trips_since_walk = 0;
-				intersect_grids(objs, P.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, P.debug_flags, P.debug_counters);
+				intersect_grids(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters);
 				waiting = false;
 			}
 			RMD_TSTAMP(tt_walk)
 			complete = want && !waiting;
 			t = part_t, oi = part_obj, sub = part_sub;
 		} else {
-			oi = scene_intersect_wave<false>(objs, P.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, P.debug_flags, P.debug_counters);
+			oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, Pt.debug_flags, Pt.debug_counters);
 			complete = want;
 		}
 		bool terminal = lens_failed || cut;
@@ -345,7 +370,7 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 					// returns NaN and this kernel 0).
 					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
 					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
-					if (depth == P.bounce_limit && finite_inputs) {
+					if (depth == Pt.bounce_limit && finite_inputs) {
 						terminal = true; // L = 0
 					} else {
 						if constexpr (GRID) parked[0] = normal.x, parked[64] = normal.y, parked[128] = normal.z, parked[192] = t, parked_obj[0] = oi;
@@ -361,7 +386,7 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 			if constexpr (to_buffer) {
 				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
 				// sample's store travels alone, and a 24-byte store that straddles sectors was costing 2.7x its size in L2 write-backs
-				double *dst = P.sample_buf + (((size_t)wt * P.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
+				double *dst = Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
 				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
 			} else {
 				acc = acc + L; // src/trace.rs:203
