@@ -266,7 +266,9 @@ def main():
             bps = 24.0 / spp
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
         # <MODE, GRID> as rocprofv3 prints it: launches split every tile's samples over several waves (MODE 1) + the ordered sum
-        kname = "rmd::render_kernel<%s> + rmd::sum_kernel" % ("1, true, true" if scenes.CONFIGS[name][0] != "reflective_spheres" else "1, false, false")
+        # mesh scenes: persistent render kernel + sum_kernel; spheres: the render kernel's waves add the samples themselves
+        kname = ("rmd::render_kernel<1, true, true> + rmd::sum_kernel" if scenes.CONFIGS[name][0] != "reflective_spheres"
+                 else "rmd::render_kernel<1, false, false> (ordered sample sum inside)")
         out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"]}
         traffic = load_traffic(name, spp) if world == 1 else None
         rl = {

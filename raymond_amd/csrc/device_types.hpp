@@ -86,6 +86,7 @@ struct RenderParams {
 	uint32_t debug_flags;      // diagnostics (RMD_DEBUG env): 1 = skip triangle tests, 2 = skip grid walks (timing only, wrong results), 8 = count walk events
 	unsigned long long *debug_counters; // 16 counters, only touched when debug_flags & 8
 	uint32_t *work_counter;             // persistent launches: the next work item (zeroed by the host before the launch)
+	uint32_t *tile_done;                // split launches: finished waves per wave tile (zeroed by the host); the last one adds the tile's samples
 };
 
 // List mode (probe): one lane per explicit (x, y, sample).

@@ -38,6 +38,8 @@ struct rmd_context {
 	size_t wavefront_ws_bytes = 0;
 	void *d_cuq_ws = nullptr; // work-item counter + error flag of grid mode 2 (cuqueue.hip)
 	uint32_t *d_work_counter = nullptr; // next work item of a persistent launch (render_kernel.hpp)
+	uint32_t *d_tile_done = nullptr;    // split launches: finished waves per wave tile (render_kernel.hpp)
+	size_t tile_done_words = 0;
 	unsigned long long *d_debug_counters = nullptr; // walk diagnostics (DIAG builds, RMD_DEBUG=8|16)
 	// Tunables (include/raymond_hip.h: rmd_context_set_tunable).  Defaults come from the environment, read ONCE when the
 	// context is created; none of them changes a result.

@@ -386,8 +386,15 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 			if constexpr (to_buffer) {
 				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
 				// sample's store travels alone, and a 24-byte store that straddles sectors was costing 2.7x its size in L2 write-backs
-				double *dst = Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
-				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+				RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
+				// written through to memory (device scope) when a wave of this kernel adds the tile's samples (below): that wave may run on
+				// another XCD, whose L2 does not see this one's dirty lines
+				if (GRID || Pt.tile_done == nullptr) dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+				else {
+					__hip_atomic_store(dst + 0, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(dst + 1, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 			} else {
 				acc = acc + L; // src/trace.rs:203
 				s++;
@@ -404,6 +411,42 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 	}
 #endif
 #undef RMD_TSTAMP
+	if constexpr (to_buffer && !GRID) { // (mesh scenes keep sum_kernel: api.cpp)
+		// The wave that finishes a wave tile's last sample range adds the tile's samples to the pixels, strictly in sample order
+		// (src/trace.rs:203: the reference's sequential sum, bit for bit) — inside this kernel, where the reads (bandwidth) overlap the
+		// other waves' arithmetic; as a kernel of its own the sum cost 5.5 ms per 1080p / 500 spp frame.  Release: this wave's sample
+		// stores are write-through and complete (vmcnt 0) before its count; acquire: the last wave invalidates its caches before it reads.
+		if (P.tile_done != nullptr && wt < P.n_work) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			uint32_t before = 0;
+			if (lane == 0u) before = __hip_atomic_fetch_add(P.tile_done + wt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+			if (before + 1u == P.split_k) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				const uint32_t lx = lane & 7u, ly = lane >> 3;
+				if (lx < tile.w && ly < tile.h) {
+					const size_t pix = ((size_t)(tile.x0 + lx) + (size_t)(tile.y0 + ly) * P.W) * 3;
+					V3 sum = ld3(out + pix);
+					const RMD_GLOBAL double *src = (const RMD_GLOBAL double *)P.sample_buf + ((size_t)wt * P.sample_count * 64u + lane) * kSampleStride;
+					// 16 samples' loads in flight at a time (the additions stay in sample order)
+					uint32_t k = 0;
+					for (; k + 16u <= P.sample_count; k += 16u) {
+						V3 v[16];
+#pragma unroll
+						for (uint32_t j = 0; j < 16u; j++) v[j] = ld3(src + (size_t)j * 64u * kSampleStride);
+#pragma unroll
+						for (uint32_t j = 0; j < 16u; j++) sum = sum + v[j];
+						src += 16u * 64u * kSampleStride;
+					}
+					for (; k < P.sample_count; k++) {
+						sum = sum + ld3(src);
+						src += 64u * kSampleStride;
+					}
+					out[pix + 0] = sum.x, out[pix + 1] = sum.y, out[pix + 2] = sum.z;
+				}
+			}
+		}
+	}
 	if (writes && !to_buffer) {
 		out[out_index + 0] = acc.x;
 		out[out_index + 1] = acc.y;
