@@ -469,6 +469,34 @@ def test_tile_shards_sum_to_the_full_image(gpu_ctx, small_mesh_scene):
     full.close(), part.close(), ds.close()
 
 
+def test_spheres_sum_inside_the_kernel_matches_the_direct_mode(gpu_ctx, oracle):
+    """Split launches of the spheres kernel add a tile's samples inside the render kernel (the wave that finishes the tile last):
+    whatever the split, over several passes of a capped scratch buffer, on ragged tiles and on top of previous contents, the frame
+    is the one the direct mode (one wave per tile, the lane keeps its pixel's sum) and the oracle give, bit for bit."""
+    sc = scenes.reflective_spheres()
+    st = Settings(scenes.camera(203, 117), sample_count=40, bounce_limit=5, seed=77)  # 203 x 117: ragged wave tiles on both edges
+    cam = st.camera_settings
+    tiles = generate_tiles(203, 117, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, 203, 117)
+    base = np.random.default_rng(3).uniform(0, 1, (117, 203, 3))
+    want = base + oracle.OracleScene(sc).render_tiles(cam, st, tiles, threads=4)
+    out = {}
+    bytes_per_sample = ((203 + 7) // 8) * ((117 + 7) // 8) * 64 * 32
+    for split, cap_mb in ((1, 0), (0, 0), (2, 0), (5, 0), (10, 0), (5, max(1, (bytes_per_sample * 16) >> 20))):
+        gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, cap_mb)
+        try:
+            fb.upload(base)
+            render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+            out[(split, cap_mb)] = fb.download()
+        finally:
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, 0)
+    for key, img in out.items():
+        assert img.tobytes() == out[(1, 0)].tobytes(), key
+    assert rel_close(out[(1, 0)], want, 1e-9).mean() > 0.999
+    fb.close(), ds.close()
+
+
 def test_host_buffer_entry_point_matches_device_path(gpu_ctx):
     import ctypes as C
 
