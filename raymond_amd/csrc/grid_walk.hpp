@@ -517,11 +517,8 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			search(0u, own, rec_index);
 			for (uint32_t base = 0; base < total; base += 64u) {
 				const uint32_t w = base + lane;
-				bool h = false;
-				double t = 0.0;
-				uint32_t tri = 0;
-				TriRecord r = {};
-				if (w < total) r = load_record(runs + (size_t)rec_index * 80u);
+				// every lane loads a record (a lane without a test: record 0) and tests it — no zero-filled stand-in, no branch around the loads
+				const TriRecord r = load_record(runs + (size_t)rec_index * 80u);
 				// the owner lane's ray, straight from its registers (every lane takes part in the permute)
 				const int src = (int)((own & 63u) << 2);
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
@@ -536,10 +533,9 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				// is only "used" after this chunk's tests.
 				prefetched = *reinterpret_cast<const RMD_GLOBAL uint32_t *>(runs + (size_t)rec_index * 80u);
 #endif
-				if (w < total) {
-					tri = r.tri;
-					h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t);
-				}
+				double t = 0.0;
+				const uint32_t tri = r.tri;
+				const bool h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t) && w < total;
 				RMD_STAMP(5)
 				asm volatile("" ::"v"(prefetched));
 				unsigned long long hits = __ballot(h);
