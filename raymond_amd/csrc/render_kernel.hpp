@@ -277,11 +277,13 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 			}
 			prim = false;
 		}
+		// the shading inputs of the hit a lane carries — evaluated for every lane, used by next_ray for the lanes that shade (a lane
+		// without a hit reads object 0 and whatever its slots hold: cheaper than nine register moves of stand-in values per trip)
 		NextRayShadeIn hit;
-		hit.normal = hit_normal, hit.frag = ro, hit.color = ro, hit.roughness = 0.0, hit.metal = 0.0;
-		if (to_shade) {
-			if constexpr (GRID) hit.normal = mk(parked[0], parked[64], parked[128]), hit_t = parked[192], hit_obj = parked_obj[0];
-			const DevObject &o = lobjs[hit_obj];
+		if constexpr (GRID) hit_normal = mk(parked[0], parked[64], parked[128]), hit_t = parked[192], hit_obj = parked_obj[0];
+		{
+			const DevObject &o = lobjs[to_shade ? hit_obj : 0];
+			hit.normal = hit_normal;
 			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
 			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
 		}
