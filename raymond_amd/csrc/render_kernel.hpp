@@ -37,7 +37,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	uint32_t sub = 0;
 	for (uint32_t i = 0; i < n_objects; i++) {
 		const DevObject &o = objs[i];
-		double t = 0.0;
+		double t; // set by a hit and only read after one: no stand-in value (it cost a 64-bit move per object and nesting level)
 		uint32_t tri = 0;
 		bool hit = false;
 		if (o.geometry_kind == 0u) {

@@ -19,7 +19,7 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 	bool enters = false;
 	for (uint32_t i = 0; i < n_objects; i++) {
 		const DevObject &o = objs[i];
-		double t = 0.0;
+		double t; // set by a hit and only read after one
 		bool hit = false;
 		if (o.geometry_kind == 0u) {
 			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
