@@ -116,6 +116,41 @@ def test_rccl_entry_points_world_of_one(gpu_ctx):
     fb.close()
 
 
+def test_torch_rccl_collectives_world_of_one():
+    """bench.py's two ways of assembling the frame, through torch.distributed's nccl (= RCCL) backend on device tensors with a
+    world of one — the only world RCCL accepts on a one-GPU box: the calls, tensor shapes and views are the ones an N-rank run makes.
+    (In a child process: torch cannot initialise the GPU in a process that has loaded libraymond_hip.so's own ROCm runtime.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from raymond_amd import shard
+from raymond_amd.scene import generate_tiles
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29591")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+W, H = 203, 117
+tiles = generate_tiles(W, H, (32, 32))
+fb = torch.rand(W * H * 3, dtype=torch.float64, device=dev)
+want = fb.clone()
+g = shard.OwnedTileGather(torch, W, H, tiles, 0, 1, dev, root=0)
+g(dist, fb)
+shard.reduce_framebuffer(dist, fb, root=0)
+torch.cuda.synchronize()
+assert torch.equal(fb, want)
+assert g.pack(fb).shape == (W * H, 3)
+dist.destroy_process_group()
+print("collectives ok")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "collectives ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_gpu_grid_build_is_byte_identical_to_the_host_builder(gpu_ctx, oracle):
     """SURVEY.md section 8f N4: AccGrid::build_from_mesh on the GPU (atomics + scan + per-cell sort) == host builder == oracle."""
     from raymond_amd import lib
