@@ -272,8 +272,9 @@ def test_scene_intersect_spheres(gpu_ctx, oracle):
 def test_planes_special_rays_bit_exact(gpu_ctx, oracle):
     """Scene::intersect over axis-aligned, non-unit and slanted planes plus a sphere: closest object and distance bit for bit,
     including direction components with an all-ones significand, origins exactly on a plane, zero / tiny / negative-zero
-    direction components and -0.0 in a normal.  (Written for a variant that intersected axis-aligned planes through one shared
-    reciprocal per axis — bit-exact, fewer instructions, but slower: DESIGN.md "measured and rejected".)"""
+    direction components, -0.0 in a normal and non-finite rays (0 * inf and 0 * NaN are NaN in the reference's dot products: such a
+    ray misses an axis-aligned plane).  (Two short forms for axis-aligned planes were measured against these cases and dropped —
+    shared reciprocals per axis, and single-component dot products: DESIGN.md "measured and rejected".)"""
     from raymond_amd.scene import Material, Object, Plane, Scene, Sphere
 
     sc = Scene()
@@ -301,6 +302,14 @@ def test_planes_special_rays_bit_exact(gpu_ctx, oracle):
     rays[448:512, 1] = -1.0  # origin on the floor plane: numerator zero
     rays[512:576, 0] = 2.0   # origin on the right wall
     rays[576:640, :3] = [0.0, 1.75, 0.0]
+    # non-finite rays (the reference's products 0 * inf and 0 * NaN are NaN: such a ray misses an axis-aligned plane that a
+    # test reading only "its" component would report) — one per wave of 64 and whole waves of them
+    rays[700, 3] = np.nan
+    rays[770, 5] = np.inf
+    rays[840, 0] = -np.inf
+    rays[910, 1] = np.nan
+    rays[960:1024, 3] = np.nan
+    rays[1024:1088, 2] = np.inf
     dobj, dt, dsub = probe.scene_intersect(gpu_ctx, render.DeviceScene(gpu_ctx, sc), rays)
     oobj, ot, osub = oracle.OracleScene(sc).scene_intersect(rays)
     assert np.array_equal(dobj, oobj)
