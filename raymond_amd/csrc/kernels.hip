@@ -1,6 +1,8 @@
 // HIP kernels of the radiance integrator for gfx950 (CDNA4).
 //
-// render_kernel<MODE=tiles|tiles-buffered, GRID> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel.
+// render_kernel<MODE=tiles|tiles-buffered, GRID, PERSIST> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel
+//   (split launches: per (tile, sample range) work item, lanes drawing (pixel, sample) pairs from the wave's pool; grid scenes:
+//   persistent 16-wave workgroups whose waves draw the work items from a counter).
 //   Each lane runs the reference's per-pixel loop (src/trace.rs:197-205) for `sample_count` consecutive samples as an
 //   iterative state machine: a lane whose path ends regenerates the next sample's primary ray in place (in-lane path
 //   regeneration), so the wave stays full until the last samples.  trace()'s recursion (src/trace.rs:232-320) becomes a
@@ -11,7 +13,8 @@
 //   MFMA is not used: there is no dense contraction anywhere on this path.
 // (The kernel template itself is in render_kernel.hpp; its list instantiation — an explicit (x, y, sample) per lane, for the
 // parity probes — and the probe kernels are compiled into libraymond_hip_probe.so from probe_kernels.hip, not into this library.)
-// sum_kernel, tonemap_kernel — the ordered per-sample sum of split launches and the output stage.
+// sum_kernel, tonemap_kernel — the ordered per-sample sum of split launches of mesh scenes (the spheres kernel does it itself) and
+// the output stage.
 #include <hip/hip_runtime.h>
 
 #include "render_kernel.hpp"
