@@ -415,11 +415,11 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 	} else if (n_wave_tiles != 0) {
 		// work items per wave slot.  Mesh scenes run as persistent workgroups whose waves draw items from a counter: about 64 items
 		// per slot level the tail (tools/split_sweep.py, full C3 frame: 512.8 ms at 32, 508.1 at 64 .. 128, 517.8 at 500), of at
-		// least 4 samples; the spheres kernel launches one wave per item: 28 per slot, at least 8 samples
+		// least 4 samples; the spheres kernel launches one wave per item: 28 per slot, at least 32 samples
 		const uint32_t waves_per_slot = has_grid ? 64u : 28u;
 		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
-		const uint32_t min_samples = has_grid ? 4u : 8u;
+		const uint32_t min_samples = has_grid ? 4u : 32u; // spheres kernel: waves of fewer than ~32 samples lose more in their ramp and tail than finer items gain (tools/split_sweep.py)
 		if (k > sample_count / min_samples) k = sample_count / min_samples;
 	}
 	if (k > 64u) k = 64u;
