@@ -175,11 +175,12 @@ enum {
 	RMD_TUNE_SAMPLE_SPLIT = 0, /* RMD_SAMPLE_SPLIT: waves a wave tile's sample range is split over (0 = automatic)  */
 	RMD_TUNE_WALK_BATCH = 1,   /* RMD_WALK_BATCH: lanes of a wave that wait for a grid walk before one is run        */
 	RMD_TUNE_MASK_BUDGET = 2,  /* RMD_MASK_BUDGET: LDS bytes for the grids' occupancy masks (read by rmd_scene_create) */
-	RMD_TUNE_GRID_MODE = 3,    /* RMD_GRID_MODE: schedule of scenes with grids.  0 = megakernel (one wave = 64 paths + their
-	                              walks) as persistent workgroups, one per CU, whose waves draw work items from a counter;
+	RMD_TUNE_GRID_MODE = 3,    /* RMD_GRID_MODE: launch form / schedule.  0 = the megakernel (one wave = 64 paths + their walks) as
+	                              persistent workgroups, one per CU, whose waves draw work items from a counter — launches with
+	                              fewer items than the device has wave slots as one wave per item; 3 / "per-item" = always one wave
+	                              per item; 4 / "persistent" = always persistent workgroups.  Scenes with grids only:
 	                              1 / "wavefront" = streaming pipeline with path state in HBM; 2 / "cuqueue" = persistent
-	                              workgroups of tracer and walker waves around a ray queue in the CU's LDS; 3 / "per-item" =
-	                              the megakernel with one wave per work item (4-wave workgroups)                            */
+	                              workgroups of tracer and walker waves around a ray queue in the CU's LDS                  */
 	RMD_TUNE_SCRATCH_CAP_MB = 4, /* RMD_SCRATCH_CAP_MB: cap of the per-sample scratch of split launches, MiB (0 = a quarter of HBM);
 	                              a launch whose samples do not fit runs as several passes                              */
 	RMD_TUNE_CUQ_TRACERS = 5,  /* RMD_CUQ_TRACERS: tracer waves among the 16 of a CU in grid mode 2 (0 = the library's choice)  */

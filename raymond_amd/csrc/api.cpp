@@ -66,7 +66,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_MASK_BUDGET] = env_int("RMD_MASK_BUDGET");
 		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
 		const char *mode = std::getenv("RMD_GRID_MODE");
-		ctx->tunable[RMD_TUNE_GRID_MODE] = !mode ? 0 : (std::strcmp(mode, "wavefront") == 0 || std::strcmp(mode, "1") == 0) ? 1 : (std::strcmp(mode, "cuqueue") == 0 || std::strcmp(mode, "2") == 0) ? 2 : (std::strcmp(mode, "per-item") == 0 || std::strcmp(mode, "3") == 0) ? 3 : 0;
+		ctx->tunable[RMD_TUNE_GRID_MODE] = !mode ? 0 : (std::strcmp(mode, "wavefront") == 0 || std::strcmp(mode, "1") == 0) ? 1 : (std::strcmp(mode, "cuqueue") == 0 || std::strcmp(mode, "2") == 0) ? 2 : (std::strcmp(mode, "per-item") == 0 || std::strcmp(mode, "3") == 0) ? 3 : (std::strcmp(mode, "persistent") == 0 || std::strcmp(mode, "4") == 0) ? 4 : 0;
 		ctx->tunable[RMD_TUNE_CUQ_TRACERS] = env_int("RMD_CUQ_TRACERS");
 #if RMD_DIAG
 		ctx->debug_flags = (uint32_t)env_int("RMD_DEBUG"); // DIAG builds only: 1 | 2 are timing ablations that change results, 8 | 16 count events
@@ -399,27 +399,24 @@ rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *
 	return RMD_OK;
 }
 
-// A wave owns 64 pixels x its sample range.  Splitting every tile's samples over K waves that store per-sample radiance to an HBM
-// scratch buffer — sum_kernel then adds them in sample order, bit-identical to the unsplit launch
-// (tests/test_gpu_parity.py::test_sample_split_is_bit_exact) — buys two things: enough waves to fill 256 CUs evenly when wave tiles
-// are few (an N-way shard) or very uneven (a mesh), and lanes that draw (pixel, sample) items from the wave's pool instead of
-// idling until the tile's longest pixel is done.  Measured optimum (tools/split_sweep.py, shares of 1, 1/2, 1/4 and 1/8 of the
-// 1080p frame): about 28 waves per resident wave slot for the spheres kernel (full frame K = 4: 120.2 vs 121.8 ms unsplit; half
-// frame K = 8: 60.9 vs 65.5) and about 24 for the mesh kernel (full frame K = 4: 117.3 vs 120.1 with K = 2), as long as a wave keeps
-// at least 8 samples.  RMD_TUNE_SAMPLE_SPLIT forces K.
+// A work item is (wave tile, sample range): a tile's samples are split over K items whose waves store per-sample radiance to an HBM
+// scratch buffer, added to the pixels in sample order afterwards (by the wave that finishes a tile last, or by sum_kernel) — bit-identical
+// to the unsplit launch (tests/test_gpu_parity.py::test_sample_split_is_bit_exact).  It buys enough items to level the launch over 256 CUs
+// when wave tiles are few (an N-way shard) or very uneven (a mesh), and lanes that draw (pixel, sample) pairs from the item's pool instead
+// of idling until the tile's longest pixel is done.  RMD_TUNE_SAMPLE_SPLIT forces K.
 static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_wave_tiles, uint32_t sample_count) {
 	uint32_t k = 1;
 	if (ctx->tunable[RMD_TUNE_SAMPLE_SPLIT] > 0) {
 		k = (uint32_t)ctx->tunable[RMD_TUNE_SAMPLE_SPLIT];
 		if (k > sample_count / 4u) k = sample_count / 4u; // a forced split keeps >= 4 samples (256 pool items) per wave
 	} else if (n_wave_tiles != 0) {
-		// work items per wave slot.  Mesh scenes run as persistent workgroups whose waves draw items from a counter: about 64 items
-		// per slot level the tail (tools/split_sweep.py, full C3 frame: 512.8 ms at 32, 508.1 at 64 .. 128, 517.8 at 500), of at
-		// least 4 samples; the spheres kernel launches one wave per item: 28 per slot, at least 32 samples
-		const uint32_t waves_per_slot = has_grid ? 64u : 28u;
+		// about 64 work items per wave slot level the tail of a launch of persistent workgroups (tools/split_sweep.py — full C3 frame:
+		// 512.8 ms at 32, 508.1 at 64 .. 128, 517.8 at 500; full C2 frame: 112.9 at 32, 112.0 at 64 .. 128, 113.6 at 256), of at least
+		// 4 samples (mesh) / 16 samples (spheres) each
+		const uint32_t waves_per_slot = 64u;
 		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
-		const uint32_t min_samples = has_grid ? 4u : 32u; // spheres kernel: waves of fewer than ~32 samples lose more in their ramp and tail than finer items gain (tools/split_sweep.py)
+		const uint32_t min_samples = has_grid ? 4u : 16u;
 		if (k > sample_count / min_samples) k = sample_count / min_samples;
 	}
 	if (k > 64u) k = 64u;
@@ -466,9 +463,10 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	// grid mode 2: persistent tracer / walker workgroups (cuqueue.hip); it writes per-sample output, i.e. it needs a split launch
 	const bool use_cuq = scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 2 && split > 1u && !(P.debug_flags & 16u);
 	if (use_cuq && !ctx->d_cuq_ws) RMD_HIP(ctx, hipMalloc(&ctx->d_cuq_ws, rmd::cuq_workspace_bytes()));
-	// grid scenes, default mode: the megakernel as persistent workgroups, one per CU, whose waves draw their work items from a counter
-	// (mode 3: one wave per work item, 4-wave workgroups — the form of round 1; 4.7 % slower on the benchmark mesh)
-	const bool persistent = scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 0 && !use_cuq;
+	// default mode: the megakernel as persistent workgroups, one per CU, whose waves draw their work items from a counter
+	// (mode 3: one wave per work item — the form of round 1; 4.7 % slower on the benchmark mesh, 2.4 % on the spheres frame, where a
+	// workgroup launch per item cost ~100 us of a wave slot each: 152 vs 113.6 ms at 32 items per wave tile)
+	const bool persistent = (ctx->tunable[RMD_TUNE_GRID_MODE] == 0 || ctx->tunable[RMD_TUNE_GRID_MODE] == 4) && !use_cuq;
 	if (persistent && !ctx->d_work_counter) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_work_counter, 256));
 	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes.  It may take a quarter of the
 	// device's HBM (72 GiB of 288: the whole C3 frame at 500 spp is 24.9 GB, one launch); what does not fit runs as several passes
@@ -500,7 +498,9 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			                                    (uint32_t)ctx->tunable[RMD_TUNE_CUQ_TRACERS]));
 			continue;
 		}
-		if (persistent) {
+		// (a launch with fewer work items than the device has wave slots spreads better as one wave per item)
+		const bool persistent_pass = persistent && ((uint64_t)P.n_work * Q.split_k >= ctx->wave_slots || ctx->tunable[RMD_TUNE_GRID_MODE] == 4);
+		if (persistent_pass) {
 			RMD_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));
 			Q.work_counter = ctx->d_work_counter;
 		}
@@ -517,7 +517,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			RMD_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, (size_t)P.n_work * sizeof(uint32_t), ctx->stream));
 			Q.tile_done = ctx->d_tile_done;
 		}
-		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent ? ctx->n_cus : 0u));
+		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent_pass ? ctx->n_cus : 0u));
 		if (settings->sample_count == 0) break;
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -539,7 +539,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value) {
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: null context");
 	if (key >= RMD_TUNE_COUNT || value < 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: unknown key or negative value");
-	if (key == RMD_TUNE_GRID_MODE && value > 3) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: grid mode is 0, 1, 2 or 3");
+	if (key == RMD_TUNE_GRID_MODE && value > 4) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: launch mode is 0 .. 4");
 	if (key == RMD_TUNE_CUQ_TRACERS && value > 15) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: 1..15 tracer waves");
 	ctx->tunable[key] = value;
 	return RMD_OK;

@@ -84,8 +84,8 @@ hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const 
 	hipError_t e;
 	if (P.n_grids) e = buffered ? launch_render<kModeTilesBuffered, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus)
 	                            : launch_render<kModeTiles, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus);
-	else e = buffered ? launch_render<kModeTilesBuffered, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr)
-	                  : launch_render<kModeTiles, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr);
+	else e = buffered ? launch_render<kModeTilesBuffered, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus)
+	                  : launch_render<kModeTiles, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus);
 	if (e != hipSuccess || !buffered || P.tile_done != nullptr) return e; // with tile_done the render kernel's waves add the samples themselves
 	hipLaunchKernelGGL(sum_kernel, dim3(P.n_work), dim3(64), 0, stream, P, wave_tiles, (const double *)P.sample_buf, accum);
 	return hipGetLastError();

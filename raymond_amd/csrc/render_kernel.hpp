@@ -461,7 +461,7 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 // counter (P.work_counter, zeroed by the host) until none is left — the masks cost one copy per CU instead of one per
 // 4-wave workgroup, which leaves each wave 8 KB of LDS, and no wave slot idles while the rest of a workgroup finishes.
 template <int MODE, bool GRID, bool PERSIST>
-__global__ __launch_bounds__(GRID ? 64 * (PERSIST ? kPersistWavesPerWg : kGridWavesPerWg) : 64, GRID ? RMD_GRID_MINW : RMD_NOGRID_MINW) void render_kernel(
+__global__ __launch_bounds__(PERSIST ? 64 * kPersistWavesPerWg : GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_MINW : (PERSIST ? 4 : RMD_NOGRID_MINW)) void render_kernel(
     RenderParams P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work, double *__restrict__ out,
     int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub) {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(GRID ? 64 * (PERSIST ? kPersistWavesPerWg : kGridWa
 template <int MODE, bool GRID>
 inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
                                 uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub, uint32_t n_cus = 0) {
-	if constexpr (GRID && MODE != kModeList) {
+	if constexpr (MODE != kModeList) {
 		if (n_cus != 0u && P.work_counter != nullptr && render_lds_bytes(P.n_objects, P.mask_words_total, kPersistWavesPerWg) <= kLdsBudgetBytes) {
 			const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, kPersistWavesPerWg);
 			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>), hipFuncAttributeMaxDynamicSharedMemorySize,

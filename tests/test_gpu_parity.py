@@ -492,17 +492,20 @@ def test_spheres_sum_inside_the_kernel_matches_the_direct_mode(gpu_ctx, oracle):
     want = base + oracle.OracleScene(sc).render_tiles(cam, st, tiles, threads=4)
     out = {}
     bytes_per_sample = ((203 + 7) // 8) * ((117 + 7) // 8) * 64 * 32
-    for split, cap_mb in ((1, 0), (0, 0), (2, 0), (5, 0), (10, 0), (5, max(1, (bytes_per_sample * 16) >> 20))):
+    cap = max(1, (bytes_per_sample * 16) >> 20)
+    # launch mode 3 = one wave per work item, 4 = persistent workgroups (what full-size frames get)
+    for split, cap_mb, mode in ((1, 0, 3), (1, 0, 4), (0, 0, 0), (2, 0, 3), (5, 0, 4), (10, 0, 3), (10, 0, 4), (5, cap, 3), (5, cap, 4)):
         gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, cap_mb)
+        gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, mode)
         try:
             fb.upload(base)
             render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
-            out[(split, cap_mb)] = fb.download()
+            out[(split, cap_mb, mode)] = fb.download()
         finally:
-            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, 0)
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, 0)
     for key, img in out.items():
-        assert img.tobytes() == out[(1, 0)].tobytes(), key
-    assert rel_close(out[(1, 0)], want, 1e-9).mean() > 0.999
+        assert img.tobytes() == out[(1, 0, 3)].tobytes(), key
+    assert rel_close(out[(1, 0, 3)], want, 1e-9).mean() > 0.999
     fb.close(), ds.close()
 
 
@@ -764,9 +767,10 @@ def test_cu_queue_mode_is_bit_identical(gpu_ctx, small_mesh_scene, oracle):
         ds = render.DeviceScene(gpu_ctx, sc)
         fb = render.Framebuffer(gpu_ctx, W, H)
         out = {}
-        # mode 0 = persistent workgroups drawing work items from a counter (the default), 3 = one wave per work item, 2 = CU queue;
+        # mode 0 = the library's choice (one wave per work item for frames this small), 4 = persistent workgroups drawing work items
+        # from a counter (what full-size frames get), 3 = one wave per work item, 2 = CU queue;
         # (mode, forced split): 0 = the library's choice (direct mode for these few samples), 3 = three waves per wave tile
-        for mode, split in ((0, 0), (2, 0), (3, 0), (0, 3), (3, 3)):
+        for mode, split in ((0, 0), (2, 0), (3, 0), (4, 0), (0, 3), (3, 3), (4, 3)):
             gpu_ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, mode), gpu_ctx.set_tunable(abi.RMD_TUNE_CUQ_TRACERS, tracers)
             gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
             try:
