@@ -268,7 +268,7 @@ def main():
         # <MODE, GRID> as rocprofv3 prints it: launches split every tile's samples over several waves (MODE 1) + the ordered sum
         # mesh scenes: persistent render kernel + sum_kernel; spheres: the render kernel's waves add the samples themselves
         kname = ("rmd::render_kernel<1, true, true> + rmd::sum_kernel" if scenes.CONFIGS[name][0] != "reflective_spheres"
-                 else "rmd::render_kernel<1, false, false> (ordered sample sum inside)")
+                 else "rmd::render_kernel<1, false, true> (persistent workgroups, ordered sample sum inside)")
         out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"]}
         traffic = load_traffic(name, spp) if world == 1 else None
         rl = {
