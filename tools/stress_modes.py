@@ -1,0 +1,32 @@
+"""The full C3 frame in every launch form (0 = persistent workgroups, 3 = one wave per work item) and several splits, N frames each: every
+frame must equal the first one bit for bit (work items are drawn in a different order on every run).  python tools/stress_modes.py [frames] [spp]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raymond_amd import abi, render, scenes
+from raymond_amd.scene import generate_tiles
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+st = scenes.config_settings("C3", spp=spp)
+cam = st.camera_settings
+sc = getattr(scenes, scenes.CONFIGS["C3"][0])()
+tiles = generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size)
+with render.Context(0) as ctx:
+    ds = render.DeviceScene(ctx, sc)
+    fb = render.Framebuffer(ctx, cam.backbuffer_width, cam.backbuffer_height)
+    want, bad = None, 0
+    for mode in (0, 3):
+        for split in (0, 2, 7):
+            ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, mode), ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
+            for i in range(frames):
+                fb.zero()
+                render.render_tiles(ctx, ds, cam, st, tiles, fb)
+                got = fb.download().tobytes()
+                if want is None:
+                    want = got
+                elif got != want:
+                    bad += 1
+                    print("MISMATCH mode", mode, "split", split, "frame", i, flush=True)
+            print("mode %d split %d: %d frames, %d mismatches so far" % (mode, split, frames, bad), flush=True)
+    print("stress: %s" % ("FAILED" if bad else "ok"))
+    sys.exit(1 if bad else 0)
