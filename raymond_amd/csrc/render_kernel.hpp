@@ -209,11 +209,12 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 #define RMD_TSTAMP(acc)
 #endif
 	for (;;) {
-		// Grid kernel: the launch parameters a trip needs are read again from the kernel arguments (a few scalar loads per trip) instead
-		// of being carried in scalar registers across trips — it was spilling scalars into vector lanes all through the trip (168
-		// v_readlane / v_writelane at trip level, 41 now).  The empty asm keeps the compiler from hoisting the loads out of the loop.
+		// The launch parameters a trip needs are read again from the kernel arguments (a few scalar loads per trip) instead of being
+		// carried in scalar registers across trips — the grid kernel was spilling scalars into vector lanes all through the trip (168
+		// v_readlane / v_writelane at trip level, 41 now; 496.4 -> 487.3 ms on C3), the spheres kernel less so (112.2 -> 110.6 ms on
+		// C2).  The empty asm keeps the compiler from hoisting the loads out of the loop.
 		auto trip_params = [&]() -> decltype(auto) {
-			if constexpr (GRID && RMD_TRIP_RELOAD) {
+			if constexpr (RMD_TRIP_RELOAD) {
 				typedef const __attribute__((address_space(4))) unsigned long long *WordsInConstant;
 				// RenderParams is render_kernel's first argument: offset 0 of the kernel-argument segment
 				WordsInConstant src = (WordsInConstant)__builtin_amdgcn_kernarg_segment_ptr();
