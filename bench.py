@@ -36,14 +36,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (default: the config's)")
     ap.add_argument("--roofline-spp", type=int, default=None, help="spp of the C3 roofline leg (default: the config's 500)")
     ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = calibrate to ~15 s)")
-    ap.add_argument("--assemble", default="gather", choices=["gather", "reduce"],
-                    help="N > 1: how rank 0 gets the frame - gather of the tiles each rank owns (1/N of a frame per rank) or "
-                         "reduce(sum) of the full frames; both bit-identical to the 1-GPU frame")
+    ap.add_argument("--assemble", default="gather", choices=["gather", "reduce", "abi"],
+                    help="N > 1: how rank 0 gets the frame - gather of the tiles each rank owns (1/N of a frame per rank), "
+                         "reduce(sum) of the full frames through torch.distributed, or abi: the same reduce through the C-ABI's own "
+                         "rmd_comm_* / rmd_reduce_framebuffer (RCCL, one rank per GPU); all bit-identical to the 1-GPU frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
     return ap.parse_args()
@@ -126,16 +127,37 @@ def load_valu(name):
         return json.load(f).get(name)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as FRESH child processes, one per GPU, through
+    torch.distributed.run (the form the driver uses), let rank 0's JSON line through on stdout, and return their exit status.
+    Called before this process has imported torch or touched the GPU — a process that has initialised the GPU is never
+    re-executed; this parent only waits."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool's host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE is unset)" % args.gpus)
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
@@ -178,6 +200,23 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     ctx = render.Context(local_rank, stream=stream)
 
+    # --assemble abi: the C-ABI's own collective (rmd_comm_* over RCCL, csrc/comm.cpp) — rank 0 makes the id, everyone joins
+    abi_comm = None
+    if args.assemble == "abi":
+        from raymond_amd import abi as rabi
+
+        if world > 1 and backend != "nccl":
+            raise SystemExit("--assemble abi needs one rank per GPU (RCCL refuses two ranks on one device): not available in the gloo rehearsal")
+        uid = (C.c_uint8 * rabi.RMD_COMM_ID_BYTES)()
+        if rank == 0:
+            ctx.check(ctx.L.rmd_comm_unique_id(uid))
+        box = [bytes(uid)]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0, device=dev)
+        uid = (C.c_uint8 * rabi.RMD_COMM_ID_BYTES).from_buffer_copy(box[0])
+        abi_comm = C.c_void_p()
+        ctx.check(ctx.L.rmd_comm_create(ctx.handle, uid, rank, world, C.byref(abi_comm)))
+
     def run_workload(name, spp, steps, warmup, reduce):
         st, cam, sc, tiles, share = setup(name, spp)
         W, H = cam.backbuffer_width, cam.backbuffer_height
@@ -193,7 +232,9 @@ def main():
         def step():
             fb_t.zero_()
             render.render_tiles(ctx, ds, cam, st, arr, fb, 0, st.sample_count, sync=False)
-            if gather is not None:
+            if reduce and abi_comm is not None:
+                ctx.check(ctx.L.rmd_reduce_framebuffer(abi_comm, fb_t.data_ptr(), fb_t.numel(), 0))  # ncclReduce on the context's stream
+            elif gather is not None:
                 gather(dist, fb_t, stage_host=(backend != "nccl"))
             elif reduce and dist is not None:
                 if backend == "nccl":
@@ -252,8 +293,8 @@ def main():
             "workload": "%s: %s, %dx%d, %d spp, %d bounces, 32x32 host tiles round-robin over %d GPU(s)%s"
             % (name, scenes.CONFIGS[name][0], main_run["W"], main_run["H"], spp, main_run["st"].bounce_limit, world,
                (", RCCL gather of each rank's own tiles to rank 0" if args.assemble == "gather" else
-                ", RCCL reduce(sum) of the f64 framebuffer to rank 0") if world > 1 else ""),
-            "rng": "philox4x32-10 keyed (seed; pixel, sample, draw)",
+                ", RCCL reduce(sum) of the f64 framebuffer to rank 0" + (" through rmd_reduce_framebuffer" if args.assemble == "abi" else "")) if world > 1 else ""),
+            "rng": "philox4x32-10, key = seed, counter = (pixel, sample, block, 0); one block per consumer (jitter, lens round, shaded depth)",
             "seed": scenes.SEED,
         },
     }
@@ -348,6 +389,8 @@ def main():
         out["cpu_baseline_4_threads"] = {"value": round(cam.backbuffer_width * cam.backbuffer_height * spp4 / dt4 / 1e6, 4), "unit": "Msamples/s", "cores": 4,
                                          "kind": "port", "sample": "%s at %dx%d, %d spp, %.1f s" % (name, cam.backbuffer_width, cam.backbuffer_height, spp4, dt4)}
 
+    if abi_comm is not None:
+        ctx.L.rmd_comm_destroy(abi_comm)
     ctx.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

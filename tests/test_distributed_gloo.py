@@ -130,3 +130,20 @@ def test_owned_tile_gather_indices():
             assert bool((out[torch.from_numpy(rows[r])] == float(r + 1)).all())
     # x, y of a row: x + y * W
     assert shard.tile_pixel_rows([(64, 32, 6, 18)], W)[:7].tolist() == [64 + 32 * W + i for i in range(6)] + [64 + 33 * W]
+
+
+def test_bench_starts_its_own_ranks_without_touching_the_gpu_in_the_parent():
+    """`python bench.py --gpus 2` outside a launcher: the parent starts two fresh ranks (torch.distributed.run) before it has
+    imported torch or made a GPU call, and returns their status.  Without a GPU (this container) each RANK refuses loudly —
+    the product has no CPU fallback — and the parent's exit status is non-zero."""
+    import subprocess
+
+    if __import__("torch").cuda.is_available():
+        pytest.skip("CPU-side check of the launch route; the GPU form is test_bench_contract_and_two_rank_rehearsal")
+    env = dict(os.environ, RMD_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]  # both ranks ran bench.py's main()
+    assert "{" not in r.stdout  # no JSON line from a run that measured nothing

@@ -197,18 +197,25 @@ def test_bench_contract_and_two_rank_rehearsal(gpu_ctx):
         assert key in a, key
     assert a["unit"] == "Msamples/s" and a["n_gpus"] == 1 and a["dtype"] == "f64" and a["vs_baseline"] is None and "workload" in a["config"]
     assert abs(a["value"] - 1920 * 1080 * 24 / (a["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * a["value"]
+    # N > 1 without a launcher: bench.py starts its own ranks as fresh child processes (the form the driver uses at N = 1)
     env = dict(os.environ, RMD_BENCH_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
-                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     b = json.loads([l for l in two.stdout.split("\n") if l.startswith("{")][0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong"
     assert b["kernel"]["checksum"] == a["kernel"]["checksum"]  # default: gather of the tiles each rank owns
     assert "gather" in b["config"]["workload"]
+    # ... and under an explicit launcher, as the driver starts N > 1
     red = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29578", os.path.join(root, "bench.py"), "--gpus", "2", "--assemble", "reduce"] + common,
                          capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert red.returncode == 0, red.stderr[-2000:]
     c = json.loads([l for l in red.stdout.split("\n") if l.startswith("{")][0])
     assert c["kernel"]["checksum"] == a["kernel"]["checksum"]  # every pixel is non-zero on exactly one rank
+    # the C-ABI's own collective (rmd_comm_* / rmd_reduce_framebuffer over RCCL) with the one rank RCCL accepts on a one-GPU box
+    one_abi = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--assemble", "abi"] + common, capture_output=True, text=True, timeout=300, cwd=root)
+    assert one_abi.returncode == 0, one_abi.stderr[-2000:]
+    d = json.loads([l for l in one_abi.stdout.split("\n") if l.startswith("{")][0])
+    assert d["kernel"]["checksum"] == a["kernel"]["checksum"]
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--assemble", "abi"] + common, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert bad.returncode != 0  # two ranks on one device: refused loudly, no fallback
