@@ -364,7 +364,8 @@ def main():
         cores, quota = usable_cpus()
         # calibrate on 1 spp, then size the sample for ~15 s of CPU work (the rate is spp-independent)
         st, cam, sc, tiles, _ = setup(name, 1)
-        osc = oracle_lib.OracleScene(sc)
+        osc = oracle_lib.OracleScene(sc, fast=True)  # liboracle_fast.so: the restatement without its work counters, -O3
+        osc.render_tiles(cam, st, tiles, threads=cores)  # untimed: thread start-up, page faults
         t0 = time.perf_counter()
         osc.render_tiles(cam, st, tiles, threads=cores)
         t1 = time.perf_counter() - t0
@@ -376,7 +377,7 @@ def main():
         n = cam.backbuffer_width * cam.backbuffer_height * cpu_spp
         out["cpu_baseline"] = {
             "value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%s at %dx%d, %d spp (%.1f M samples, %.1f s): reference-equivalent C++ restatement (oracle/), worker pool of %d threads (num_cpus::get() capped by the cgroup CPU quota%s), 32x32 tiles, g++ -O2"
+            "sample": "%s at %dx%d, %d spp (%.1f M samples, %.1f s): reference-equivalent C++ restatement (oracle/), worker pool of %d threads (num_cpus::get() capped by the cgroup CPU quota%s), 32x32 tiles, g++ -O3, work counters compiled out (-DORC_NO_COUNTERS)"
             % (name, cam.backbuffer_width, cam.backbuffer_height, cpu_spp, n / 1e6, dt, cores, "" if quota is None else " of %.1f CPUs" % quota),
         }
         out["speedup_vs_cpu_baseline"] = round(value / (n / dt / 1e6), 1)
@@ -388,6 +389,24 @@ def main():
         dt4 = time.perf_counter() - t0
         out["cpu_baseline_4_threads"] = {"value": round(cam.backbuffer_width * cam.backbuffer_height * spp4 / dt4 / 1e6, 4), "unit": "Msamples/s", "cores": 4,
                                          "kind": "port", "sample": "%s at %dx%d, %d spp, %.1f s" % (name, cam.backbuffer_width, cam.backbuffer_height, spp4, dt4)}
+        # the mesh workload of the roofline leg on the same cores (the reference's README quotes its GoldDragon render at 0.101 Msamples/s on
+        # the same "4 core i5", README.md:27): ~8 s of CPU work
+        if "roofline" in out and not args.no_roofline_leg and name != "C3":
+            st3, cam3, sc3, tiles3, _ = setup("C3", 1)
+            osc3 = oracle_lib.OracleScene(sc3, fast=True)
+            t0 = time.perf_counter()
+            osc3.render_tiles(cam3, st3, tiles3, threads=cores)
+            t3 = time.perf_counter() - t0
+            spp3 = max(1, min(64, int(8.0 / max(t3, 1e-3))))
+            st3 = scenes.config_settings("C3", spp=spp3)
+            t0 = time.perf_counter()
+            osc3.render_tiles(cam3, st3, tiles3, threads=cores)
+            dt3 = time.perf_counter() - t0
+            n3 = cam3.backbuffer_width * cam3.backbuffer_height * spp3
+            out["roofline"]["cpu_baseline"] = {"value": round(n3 / dt3 / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                               "sample": "C3 at %dx%d, %d spp (%.1f M samples, %.1f s), same build and worker pool" % (cam3.backbuffer_width, cam3.backbuffer_height, spp3, n3 / 1e6, dt3)}
+            if out["roofline"].get("msamples_per_s"):
+                out["roofline"]["speedup_vs_cpu_baseline"] = round(out["roofline"]["msamples_per_s"] / (n3 / dt3 / 1e6), 1)
 
     if abi_comm is not None:
         ctx.L.rmd_comm_destroy(abi_comm)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RMD_ABI_VERSION 1u
+#define RMD_ABI_VERSION 2u
 
 typedef int32_t rmd_status;
 enum {
@@ -175,17 +175,16 @@ enum {
 	RMD_TUNE_SAMPLE_SPLIT = 0, /* RMD_SAMPLE_SPLIT: waves a wave tile's sample range is split over (0 = automatic)  */
 	RMD_TUNE_WALK_BATCH = 1,   /* RMD_WALK_BATCH: lanes of a wave that wait for a grid walk before one is run        */
 	RMD_TUNE_MASK_BUDGET = 2,  /* RMD_MASK_BUDGET: LDS bytes for the grids' occupancy masks (read by rmd_scene_create) */
-	RMD_TUNE_GRID_MODE = 3,    /* RMD_GRID_MODE: launch form / schedule.  0 = the megakernel (one wave = 64 paths + their walks) as
-	                              persistent workgroups, one per CU, whose waves draw work items from a counter — launches with
-	                              fewer items than the device has wave slots as one wave per item; 3 / "per-item" = always one wave
-	                              per item; 4 / "persistent" = always persistent workgroups.  Scenes with grids only:
-	                              1 / "wavefront" = streaming pipeline with path state in HBM; 2 / "cuqueue" = persistent
-	                              workgroups of tracer and walker waves around a ray queue in the CU's LDS                  */
-	RMD_TUNE_SCRATCH_CAP_MB = 4, /* RMD_SCRATCH_CAP_MB: cap of the per-sample scratch of split launches, MiB (0 = a quarter of HBM);
-	                              a launch whose samples do not fit runs as several passes                              */
-	RMD_TUNE_CUQ_TRACERS = 5,  /* RMD_CUQ_TRACERS: tracer waves among the 16 of a CU in grid mode 2 (0 = the library's choice)  */
-	RMD_TUNE_COUNT = 6
+	RMD_TUNE_LAUNCH_FORM = 3,  /* RMD_LAUNCH_FORM: 0 = the library's choice: persistent workgroups, one per CU, whose waves draw work
+	                              items from a counter — launches with fewer items than the device has wave slots as one wave per
+	                              item; 1 / "per-item" = always one wave per item; 2 / "persistent" = always persistent workgroups */
+	RMD_TUNE_SCRATCH_CAP_MB = 4, /* RMD_SCRATCH_CAP_MB: cap of the per-sample scratch of split launches, MiB (0 = an eighth of the
+	                              device memory that is free when the buffer is (re)allocated); a launch whose samples do not fit —
+	                              or whose buffer the device cannot provide — runs as several passes                       */
+	RMD_TUNE_COUNT = 5
 };
+/* Free and total memory of the context's device, bytes (hipMemGetInfo): what a host that shares the GPU sizes its launches by. */
+rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, uint64_t *out_total_bytes);
 rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value);
 rmd_status rmd_context_get_tunable(const rmd_context *ctx, uint32_t key, int64_t *out_value);
 

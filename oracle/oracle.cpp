@@ -72,10 +72,21 @@ enum { K_SAMPLES, K_SEGMENTS, K_CELLS, K_TRI_TESTS, K_MESH_HITS, K_BOUNCES, K_DR
 std::mutex g_counter_mutex;
 Counters g_counters;
 thread_local Counters tl_counters;
+/* -DORC_NO_COUNTERS (liboracle_fast.so, the build bench.py times as cpu_baseline): the work counters and walk histograms compile to
+ * nothing, so the timed loop is the reference's loop and not the reference's loop plus its instrumentation.  Same results bit for bit. */
+#ifdef ORC_NO_COUNTERS
+#define ORC_COUNT(k, n) ((void)0)
+#else
+#define ORC_COUNT(k, n) (tl_counters.c[k] += (n))
+#endif
 /* per-walk histograms (design instrumentation): [kind][bucket], kind 0 = cells visited, 1 = non-empty cells visited, 2 = triangle tests, 3 = max triangles in one cell */
 std::atomic<uint64_t> g_walk_hist[4][65];
 std::atomic<uint64_t> g_walk_hits{0};
+#ifdef ORC_NO_COUNTERS
+inline void hist_add(int, uint64_t) {}
+#else
 inline void hist_add(int kind, uint64_t v) { g_walk_hist[kind][v > 64 ? 64 : v]++; }
+#endif
 void flush_counters() {
 	std::lock_guard<std::mutex> lock(g_counter_mutex);
 	for (int i = 0; i < 8; i++) {
@@ -128,13 +139,13 @@ struct Rng {
 	}
 	void next2(double &u0, double &u1) { /* two rand::random::<f64>() calls */
 		double unused;
-		tl_counters.c[K_DRAWS] += 2;
+		ORC_COUNT(K_DRAWS, 2);
 		at(key, pixel, sample, block++, u0, u1, unused);
 	}
 	/* the three calls of one shaded depth, in the reference's order r, r1, r2.  r is only ever compared with prob_d = 0.5
 	 * (Diffuse) or 0.0 (Metal) (:263-264): the 22-bit uniform gives those comparisons the probabilities a 53-bit one does */
 	void next3(double &r, double &r1, double &r2) {
-		tl_counters.c[K_DRAWS] += 3;
+		ORC_COUNT(K_DRAWS, 3);
 		at(key, pixel, sample, block++, r1, r2, r);
 	}
 };
@@ -358,7 +369,7 @@ int build_from_mesh(std::vector<Triangle> tris, AccGrid &g) {
 Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 	Hit outer = aabb_intersects(g.bounding_box, ray);
 	if (!outer.some) return hit_none();
-	tl_counters.c[K_WALKS]++;
+	ORC_COUNT(K_WALKS, 1);
 	V3 outer_pos = ray.origin + ray.direction * outer.distance;
 	V3 start = ray.origin - g.bounding_box.min;
 	int32_t cx, cy, cz;
@@ -394,14 +405,17 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 	struct WalkStat {
 		uint64_t &c, &n, &t, &m;
 		bool hit = false;
+#ifndef ORC_NO_COUNTERS
 		~WalkStat() { hist_add(0, c), hist_add(1, n), hist_add(2, t), hist_add(3, m); if (hit) g_walk_hits++; }
+#endif
 	} wstat{w_cells, w_nonempty, w_tests, w_maxc};
+	(void)wstat;
 	for (;;) {
 		/* `as usize` of a negative i32 sign-extends; the index arithmetic wraps (release build) */
 		uint64_t x = (uint64_t)(int64_t)cx, y = (uint64_t)(int64_t)cy, z = (uint64_t)(int64_t)cz;
 		uint64_t idx = x + g.res[0] * (y + z * g.res[2]);
 		if (idx >= g.cells.size()) return hit_none();
-		tl_counters.c[K_CELLS]++;
+		ORC_COUNT(K_CELLS, 1);
 		uint64_t cell = g.cells[idx];
 		uint64_t count = g.mapping_table[cell];
 		w_cells++, w_tests += count, w_nonempty += count > 0, w_maxc = std::max(w_maxc, count);
@@ -409,7 +423,7 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 		Hit closest_hit = hit_none();
 		for (uint64_t i = 1; i <= count; i++) {
 			uint64_t ti = g.mapping_table[cell + i];
-			tl_counters.c[K_TRI_TESTS]++;
+			ORC_COUNT(K_TRI_TESTS, 1);
 			Hit h = triangle_intersects(g.triangles[ti], ray);
 			if (h.some) {
 				if (h.distance < closest) {
@@ -478,12 +492,12 @@ V3 geometry_normal(const Object &o, const Ray &ray, const Hit &hit) {
 	switch (o.geometry_kind) {
 	case RMD_GEOM_PLANE: return o.plane.normal;
 	case RMD_GEOM_SPHERE: return sphere_normal(o.sphere, ray, hit.distance);
-	default: tl_counters.c[K_MESH_HITS]++; return triangle_normal(o.grid->triangles[hit.subobject_index], ray, hit.distance);
+	default: ORC_COUNT(K_MESH_HITS, 1); return triangle_normal(o.grid->triangles[hit.subobject_index], ray, hit.distance);
 	}
 }
 /* scene.rs:54-74: linear closest hit, strict '<' keeps the first object on ties */
 int scene_intersect(const Scene &scene, const Ray &ray, Hit &out) {
-	tl_counters.c[K_SEGMENTS]++;
+	ORC_COUNT(K_SEGMENTS, 1);
 	double closest_distance = F_MAX;
 	int closest_object = -1;
 	for (size_t i = 0; i < scene.objects.size(); i++) {
@@ -624,7 +638,7 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 	V3 material_color = object.material.color;
 	double material_roughness = object.material.roughness;
 	double material_metalness = object.material.kind == RMD_MAT_METAL ? 1.0 : 0.0; /* :248-249 */
-	tl_counters.c[K_BOUNCES]++;
+	ORC_COUNT(K_BOUNCES, 1);
 
 	V3 cam_pos = v3(ctx.cam->position[0], ctx.cam->position[1], ctx.cam->position[2]);
 	V3 view_dir = normalize(cam_pos - fragment_position); /* :256 (Q1) */
@@ -672,7 +686,7 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 /* src/trace.rs:199-200 for one (pixel, sample) */
 V3 sample_pixel(const Scene &scene, const rmd_camera &cam, const rmd_settings &st, uint32_t x, uint32_t y, uint32_t s,
                 int32_t *path_obj = nullptr, uint32_t *path_sub = nullptr, int32_t *path_len = nullptr) {
-	tl_counters.c[K_SAMPLES]++;
+	ORC_COUNT(K_SAMPLES, 1);
 	Rng rng(st.seed, y * cam.backbuffer_width + x, s);
 	Ray primary;
 	if ((st.flags & RMD_RENDER_DOF) && cam.aperture_radius > 0.0) { /* render_tiled itself only ever calls the pinhole generator (:199) */

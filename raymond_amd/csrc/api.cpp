@@ -65,9 +65,8 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_WALK_BATCH] = env_int("RMD_WALK_BATCH");
 		ctx->tunable[RMD_TUNE_MASK_BUDGET] = env_int("RMD_MASK_BUDGET");
 		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
-		const char *mode = std::getenv("RMD_GRID_MODE");
-		ctx->tunable[RMD_TUNE_GRID_MODE] = !mode ? 0 : (std::strcmp(mode, "wavefront") == 0 || std::strcmp(mode, "1") == 0) ? 1 : (std::strcmp(mode, "cuqueue") == 0 || std::strcmp(mode, "2") == 0) ? 2 : (std::strcmp(mode, "per-item") == 0 || std::strcmp(mode, "3") == 0) ? 3 : (std::strcmp(mode, "persistent") == 0 || std::strcmp(mode, "4") == 0) ? 4 : 0;
-		ctx->tunable[RMD_TUNE_CUQ_TRACERS] = env_int("RMD_CUQ_TRACERS");
+		const char *form = std::getenv("RMD_LAUNCH_FORM");
+		ctx->tunable[RMD_TUNE_LAUNCH_FORM] = !form ? 0 : (std::strcmp(form, "per-item") == 0 || std::strcmp(form, "1") == 0) ? 1 : (std::strcmp(form, "persistent") == 0 || std::strcmp(form, "2") == 0) ? 2 : 0;
 #if RMD_DIAG
 		ctx->debug_flags = (uint32_t)env_int("RMD_DEBUG"); // DIAG builds only: 1 | 2 are timing ablations that change results, 8 | 16 count events
 #endif
@@ -189,8 +188,6 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->d_wave_tiles) (void)hipFree(ctx->d_wave_tiles);
 	if (ctx->d_sample_buf) (void)hipFree(ctx->d_sample_buf);
 	if (ctx->d_debug_counters) (void)hipFree(ctx->d_debug_counters);
-	if (ctx->d_wavefront_ws) (void)hipFree(ctx->d_wavefront_ws);
-	if (ctx->d_cuq_ws) (void)hipFree(ctx->d_cuq_ws);
 	if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
 	if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -443,47 +440,46 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		RMD_HIP(ctx, hipMemsetAsync(ctx->d_debug_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
 		P.debug_counters = ctx->d_debug_counters;
 	}
-	// Scenes with grids can also be evaluated by the streaming pipeline of wavefront.hip (RMD_GRID_MODE=wavefront):
-	// same result bit for bit, different schedule.
-	if (scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 1 && !(P.debug_flags & 24u) && (uint64_t)P.n_work * 64u < 0x7FFFFFFFull) {
-		const size_t need = rmd::wavefront_workspace_bytes(P.n_work);
-		if (need > ctx->wavefront_ws_bytes) {
-			if (ctx->d_wavefront_ws) RMD_HIP(ctx, hipFree(ctx->d_wavefront_ws));
-			ctx->d_wavefront_ws = nullptr, ctx->wavefront_ws_bytes = 0;
-			RMD_HIP(ctx, hipMalloc(&ctx->d_wavefront_ws, need));
-			ctx->wavefront_ws_bytes = need;
-		}
-		RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-		RMD_HIP(ctx, rmd::launch_wavefront(ctx->stream, P, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, ctx->d_wavefront_ws, ctx->n_cus));
-		RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
-		ctx->timed = true;
-		return RMD_OK;
-	}
-	const uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
-	// grid mode 2: persistent tracer / walker workgroups (cuqueue.hip); it writes per-sample output, i.e. it needs a split launch
-	const bool use_cuq = scene->n_grids != 0 && ctx->tunable[RMD_TUNE_GRID_MODE] == 2 && split > 1u && !(P.debug_flags & 16u);
-	if (use_cuq && !ctx->d_cuq_ws) RMD_HIP(ctx, hipMalloc(&ctx->d_cuq_ws, rmd::cuq_workspace_bytes()));
-	// default mode: the megakernel as persistent workgroups, one per CU, whose waves draw their work items from a counter
-	// (mode 3: one wave per work item — the form of round 1; 4.7 % slower on the benchmark mesh, 2.4 % on the spheres frame, where a
-	// workgroup launch per item cost ~100 us of a wave slot each: 152 vs 113.6 ms at 32 items per wave tile)
-	const bool persistent = (ctx->tunable[RMD_TUNE_GRID_MODE] == 0 || ctx->tunable[RMD_TUNE_GRID_MODE] == 4) && !use_cuq;
+	uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
+	// default form: persistent workgroups, one per CU, whose waves draw their work items from a counter (form 1: one wave per work
+	// item — round 1's; 4.7 % slower on the benchmark mesh, 2.4 % on the spheres frame, where a workgroup launch per item cost ~100 us
+	// of a wave slot each: 152 vs 113.6 ms at 32 items per wave tile)
+	const bool persistent = ctx->tunable[RMD_TUNE_LAUNCH_FORM] != 1;
 	if (persistent && !ctx->d_work_counter) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_work_counter, 256));
-	// samples per pass: the scratch buffer holds n_wave_tiles x 64 x samples x 24 bytes.  It may take a quarter of the
-	// device's HBM (72 GiB of 288: the whole C3 frame at 500 spp is 24.9 GB, one launch); what does not fit runs as several passes
+	// Samples per pass of a split launch: the scratch buffer holds n_wave_tiles x 64 x samples x 32 bytes (the whole C3 frame at 500 spp
+	// is 33 GB, one launch).  By default it may take an eighth of the device memory that is free right now (RMD_TUNE_SCRATCH_CAP_MB
+	// overrides), never less than 8 samples per pass; what does not fit runs as several passes.  The device may still refuse the
+	// allocation — other contexts, ranks or tenants hold memory, or the cap was set beyond it: the pass is then halved until a buffer
+	// can be had (the old one stays until a larger one exists), and when not even 8 samples fit the launch runs unsplit (one wave per
+	// wave tile, no scratch).  Every route gives the same frame bit for bit.
 	uint32_t per_pass = P.sample_count;
 	if (split > 1u) {
 		const size_t bytes_per_sample = (size_t)P.n_work * 64u * rmd::kSampleStride * sizeof(double);
-		size_t cap = ctx->hbm_bytes / 4;
+		size_t cap;
 		if (ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] > 0) cap = (size_t)ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] << 20;
+		else {
+			size_t free_b = 0, total_b = 0;
+			RMD_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+			cap = (free_b + ctx->sample_buf_bytes) / 8; // the buffer this context already holds counts as available to it
+		}
 		if (bytes_per_sample * per_pass > cap) per_pass = (uint32_t)(cap / bytes_per_sample);
-		if (use_cuq && (uint64_t)P.n_work * 64u * per_pass > 0xFFFFFFFFull) per_pass = (uint32_t)(0xFFFFFFFFull / ((uint64_t)P.n_work * 64u)); // 32-bit sample slots
 		if (per_pass < 8u) per_pass = 8u;
-		const size_t need = bytes_per_sample * per_pass;
-		if (need > ctx->sample_buf_bytes) {
-			if (ctx->d_sample_buf) RMD_HIP(ctx, hipFree(ctx->d_sample_buf));
-			ctx->d_sample_buf = nullptr, ctx->sample_buf_bytes = 0;
-			RMD_HIP(ctx, hipMalloc((void **)&ctx->d_sample_buf, need));
-			ctx->sample_buf_bytes = need;
+		if (per_pass > P.sample_count) per_pass = P.sample_count;
+		while (bytes_per_sample * per_pass > ctx->sample_buf_bytes) {
+			double *fresh = nullptr;
+			const hipError_t e = hipMalloc((void **)&fresh, bytes_per_sample * per_pass);
+			if (e == hipSuccess) {
+				if (ctx->d_sample_buf) (void)hipFree(ctx->d_sample_buf);
+				ctx->d_sample_buf = fresh, ctx->sample_buf_bytes = bytes_per_sample * per_pass;
+				break;
+			}
+			(void)hipGetLastError(); // the failure is handled here: it must not surface at the next launch check
+			if (e != hipErrorOutOfMemory) return rmd::fail(ctx, RMD_ERR_HIP, std::string("hipMalloc(sample scratch): ") + hipGetErrorString(e));
+			if (per_pass <= 8u) { // not even the smallest pass: render unsplit
+				split = 1u, per_pass = P.sample_count;
+				break;
+			}
+			per_pass = per_pass / 2u < 8u ? 8u : per_pass / 2u;
 		}
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
@@ -493,13 +489,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		Q.sample_count = settings->sample_count - done < per_pass ? (uint32_t)(settings->sample_count - done) : per_pass;
 		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
 		Q.sample_buf = ctx->d_sample_buf;
-		if (use_cuq && Q.split_k > 1u) {
-			RMD_HIP(ctx, rmd::launch_render_cuq(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, ctx->d_cuq_ws, ctx->n_cus,
-			                                    (uint32_t)ctx->tunable[RMD_TUNE_CUQ_TRACERS]));
-			continue;
-		}
 		// (a launch with fewer work items than the device has wave slots spreads better as one wave per item)
-		const bool persistent_pass = persistent && ((uint64_t)P.n_work * Q.split_k >= ctx->wave_slots || ctx->tunable[RMD_TUNE_GRID_MODE] == 4);
+		const bool persistent_pass = persistent && ((uint64_t)P.n_work * Q.split_k >= ctx->wave_slots || ctx->tunable[RMD_TUNE_LAUNCH_FORM] == 2);
 		if (persistent_pass) {
 			RMD_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));
 			Q.work_counter = ctx->d_work_counter;
@@ -539,14 +530,22 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value) {
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: null context");
 	if (key >= RMD_TUNE_COUNT || value < 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: unknown key or negative value");
-	if (key == RMD_TUNE_GRID_MODE && value > 4) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: launch mode is 0 .. 4");
-	if (key == RMD_TUNE_CUQ_TRACERS && value > 15) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: 1..15 tracer waves");
+	if (key == RMD_TUNE_LAUNCH_FORM && value > 2) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_set_tunable: launch form is 0 .. 2");
 	ctx->tunable[key] = value;
 	return RMD_OK;
 }
 rmd_status rmd_context_get_tunable(const rmd_context *ctx, uint32_t key, int64_t *out_value) {
 	if (!ctx || !out_value || key >= RMD_TUNE_COUNT) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_context_get_tunable: bad argument");
 	*out_value = ctx->tunable[key];
+	return RMD_OK;
+}
+
+rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, uint64_t *out_total_bytes) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!out_free_bytes || !out_total_bytes) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_context_memory_info: null pointer");
+	size_t free_b = 0, total_b = 0;
+	RMD_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+	*out_free_bytes = free_b, *out_total_bytes = total_b;
 	return RMD_OK;
 }
 
@@ -590,12 +589,49 @@ rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32
 	if (rmd_status s = bind(ctx)) return s;
 	if (!accum_dev || !out_rgb8_host || width == 0 || height == 0 || sample_count == 0)
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_resolve_tonemap: bad argument");
-	size_t n_pixels = (size_t)width * height;
+	const size_t n_pixels = (size_t)width * height;
+	if (n_pixels > 0xFFFFFFFFull) return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_resolve_tonemap: more than 2^32-1 pixels");
+	// device buffer: [rgb8: 3 n bytes, padded to 4][count: 1 word][flagged pixel indices: n words]
+	const size_t rgb_bytes = (n_pixels * 3 + 3) & ~(size_t)3;
 	uint8_t *d = nullptr;
-	RMD_HIP(ctx, hipMalloc((void **)&d, n_pixels * 3));
-	hipError_t e = rmd::launch_tonemap(ctx->stream, accum_dev, d, n_pixels, (double)sample_count, exposure, 1.0 / gamma);
+	RMD_HIP(ctx, hipMalloc((void **)&d, rgb_bytes + 4 + n_pixels * 4));
+	uint32_t *d_count = reinterpret_cast<uint32_t *>(d + rgb_bytes), *d_list = d_count + 1;
+	const double sc = (double)sample_count, inv_gamma = 1.0 / gamma;
+	uint32_t n_flagged = 0;
+	std::vector<uint32_t> list;
+	std::vector<double> px;
+	hipError_t e = hipMemsetAsync(d_count, 0, 4, ctx->stream);
+	if (e == hipSuccess) e = rmd::launch_tonemap(ctx->stream, accum_dev, d, n_pixels, sc, exposure, inv_gamma, d_list, d_count);
 	if (e == hipSuccess) e = hipMemcpyAsync(out_rgb8_host, d, n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(&n_flagged, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess && n_flagged != 0) {
+		// the pixels whose byte an ulp of exp / pow could decide: recomputed with the host libm, as the reference does every pixel
+		list.resize(n_flagged);
+		e = hipMemcpy(list.data(), d_list, (size_t)n_flagged * 4, hipMemcpyDeviceToHost);
+		const bool whole = n_flagged > 1024u; // many (a synthetic frame): one download of the frame instead of a copy per pixel
+		if (e == hipSuccess && whole) {
+			px.resize(n_pixels * 3);
+			e = hipMemcpy(px.data(), accum_dev, n_pixels * 3 * sizeof(double), hipMemcpyDeviceToHost);
+		}
+		for (uint32_t k = 0; k < n_flagged && e == hipSuccess; k++) {
+			const size_t i = list[k];
+			double a[3];
+			if (whole) a[0] = px[i * 3], a[1] = px[i * 3 + 1], a[2] = px[i * 3 + 2];
+			else e = hipMemcpy(a, accum_dev + i * 3, sizeof(a), hipMemcpyDeviceToHost);
+			if (e != hipSuccess) break;
+			double v[3];
+			bool ok = true;
+			for (int c = 0; c < 3; c++) {
+				const double p = a[c] / sc; // src/trace.rs:95
+				double tm = 1.0 - std::exp(p * -1.0 * exposure); // cli_old/src/main.rs:165
+				tm = std::pow(tm, inv_gamma);                    // :166
+				v[c] = tm * 255.0;
+				ok = ok && (v[c] > -1.0 && v[c] < 256.0); // :176 cast::<u8>()
+			}
+			for (int c = 0; c < 3; c++) out_rgb8_host[i * 3 + c] = ok ? (uint8_t)v[c] : (uint8_t)0;
+		}
+	}
 	(void)hipFree(d);
 	RMD_HIP(ctx, e);
 	return RMD_OK;

@@ -34,9 +34,6 @@ struct rmd_context {
 	uint32_t wave_slots = 0; // CUs x waves per CU the render kernels can keep resident
 	uint32_t n_cus = 0;
 	size_t hbm_bytes = 0; // totalGlobalMem of the device
-	void *d_wavefront_ws = nullptr; // path state of the streaming mode (wavefront.hip)
-	size_t wavefront_ws_bytes = 0;
-	void *d_cuq_ws = nullptr; // work-item counter + error flag of grid mode 2 (cuqueue.hip)
 	uint32_t *d_work_counter = nullptr; // next work item of a persistent launch (render_kernel.hpp)
 	uint32_t *d_tile_done = nullptr;    // split launches: finished waves per wave tile (render_kernel.hpp)
 	size_t tile_done_words = 0;

@@ -41,23 +41,34 @@ __global__ __launch_bounds__(64) void sum_kernel(RenderParams P, const WaveTile 
 }
 
 // ---------------------------------------------------------------- resolve + tone-map (cli_old/src/main.rs:161-181, src/trace.rs:95)
+// The reference's 8-bit value is trunc(255 * (1 - exp(-p * exposure))^(1/gamma)) with the HOST libm's exp and powf.  The device's exp / pow
+// differ from a host libm by an ulp or two, which can only change the byte when 255 * tm lies within a few 1e-13 of an integer.  So the
+// kernel computes every pixel and FLAGS the few whose value is within kTonemapGuard of a truncation boundary (1 .. 255); the host
+// recomputes exactly those with its libm (api.cpp: rmd_resolve_tonemap) — byte-exact output, and a pixel in ~10^6 takes the slow road.
+// Two exact cases need no flag: an argument <= -40 gives exp < 2^-57, 1 - exp = 1, pow(1, y) = 1 and 255 exactly with ANY libm
+// (saturated pixels); and values that truncate to 0 either way (|255 tm| < 1 - guard: black pixels).
 __global__ __launch_bounds__(256) void tonemap_kernel(const double *__restrict__ accum, uint8_t *__restrict__ rgb8, size_t n_pixels,
-                                                       double sample_count, double exposure, double inv_gamma) {
+                                                       double sample_count, double exposure, double inv_gamma, uint32_t *__restrict__ flagged,
+                                                       uint32_t *__restrict__ n_flagged) {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= n_pixels) return;
 	double v[3];
-	bool ok = true;
+	bool ok = true, flag = false;
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
 		double p = accum[i * 3 + c] / sample_count; // TaskHandle::await, src/trace.rs:95
-		double tm = 1.0 - exp(p * -1.0 * exposure);
+		const double arg = p * -1.0 * exposure;
+		double tm = 1.0 - exp(arg);
 		tm = pow(tm, inv_gamma);
 		v[c] = tm * 255.0;
 		ok = ok && (v[c] > -1.0 && v[c] < 256.0);
+		const double r = __builtin_rint(v[c]);
+		flag = flag || (r >= 1.0 && __builtin_fabs(v[c] - r) < kTonemapGuard && !(arg <= -40.0));
 	}
 	// Vector3<f64>.cast::<u8>() is None if any channel is NaN / out of range: the pixel then stays (0,0,0)
 #pragma unroll
 	for (int c = 0; c < 3; c++) rgb8[i * 3 + c] = ok ? (uint8_t)v[c] : (uint8_t)0;
+	if (flag) flagged[atomicAdd(n_flagged, 1u)] = (uint32_t)i; // the list has room for every pixel
 }
 
 // ---------------------------------------------------------------- launchers
@@ -98,11 +109,11 @@ hipError_t launch_sum(hipStream_t stream, const RenderParams &P, const WaveTile 
 }
 
 hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8, size_t n, double sample_count, double exposure,
-                          double inv_gamma) {
-	// n = number of pixels
+                          double inv_gamma, uint32_t *flagged, uint32_t *n_flagged) {
+	// n = number of pixels; flagged: n entries, n_flagged: one zeroed word
 	if (n == 0) return hipSuccess;
 	hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, accum, rgb8, n, sample_count, exposure,
-	                   inv_gamma);
+	                   inv_gamma, flagged, n_flagged);
 	return hipGetLastError();
 }
 

@@ -58,17 +58,10 @@ hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const D
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub);
 // pixel += the per-sample radiance of a split launch, in sample order (kernels.hip: sum_kernel)
 hipError_t launch_sum(hipStream_t stream, const RenderParams &P, const WaveTile *wave_tiles, double *accum);
-// Grid scenes through the CU-level ray queue (cuqueue.hip): persistent workgroups of tracer and walker waves; P.split_k, P.sample_buf
-// as for a split launch.  workspace: cuq_workspace_bytes() of device memory.
-size_t cuq_workspace_bytes();
-hipError_t launch_render_cuq(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const WaveTile *wave_tiles,
-                             double *accum, void *workspace, uint32_t n_cus, uint32_t n_tracers);
-// Streaming evaluation for scenes with grids (wavefront.hip).  Synchronises the stream while it polls for completion.
-size_t wavefront_workspace_bytes(uint32_t n_wave_tiles);
-hipError_t launch_wavefront(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const WaveTile *wave_tiles,
-                            double *accum, void *workspace, uint32_t n_cus);
+// |255 * tm - k| below this flags a pixel for the host's libm (kernels.hip: tonemap_kernel); device exp / pow are good to ~1e-12 there
+constexpr double kTonemapGuard = 1e-7;
 hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8, size_t n_pixels, double sample_count,
-                          double exposure, double inv_gamma);
+                          double exposure, double inv_gamma, uint32_t *flagged, uint32_t *n_flagged);
 hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in, int in_stride, double *out, int out_stride,
                         const RenderParams &P);
 hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,

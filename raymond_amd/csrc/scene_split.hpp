@@ -1,4 +1,4 @@
-// Scene::intersect (core/src/scene.rs:54-74) in two parts, shared by the schedules for scenes with grids (kernels.hip, cuqueue.hip).
+// Scene::intersect (core/src/scene.rs:54-74) in two parts, for the render loop of scenes with grids (render_kernel.hpp).
 #pragma once
 #include "device_core.hpp"
 #include "grid_walk.hpp"

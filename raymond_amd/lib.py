@@ -24,6 +24,7 @@ SIGNATURES = {
     "rmd_context_create_on_stream": (C.c_int32, [C.c_int32, _vp, _P(_vp)]),
     "rmd_context_destroy": (None, [_vp]),
     "rmd_last_error": (C.c_char_p, [_vp]),
+    "rmd_context_memory_info": (C.c_int32, [_vp, _P(C.c_uint64), _P(C.c_uint64)]),
     "rmd_context_set_tunable": (C.c_int32, [_vp, C.c_uint32, C.c_int64]),
     "rmd_context_get_tunable": (C.c_int32, [_vp, C.c_uint32, _P(C.c_int64)]),
     "rmd_scene_create": (C.c_int32, [_vp, _P(abi.Object), C.c_uint32, _P(abi.GridDesc), C.c_uint32, _P(_vp)]),

@@ -52,6 +52,12 @@ class Context:
         self.check(self.L.rmd_context_get_tunable(self.handle, key, C.byref(v)))
         return v.value
 
+    def memory_info(self):
+        """(free, total) bytes of the device's memory."""
+        free, total = C.c_uint64(), C.c_uint64()
+        self.check(self.L.rmd_context_memory_info(self.handle, C.byref(free), C.byref(total)))
+        return free.value, total.value
+
     def synchronize(self):
         self.check(self.L.rmd_context_synchronize(self.handle))
 

@@ -14,6 +14,7 @@ from raymond_amd import abi
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(_ROOT, "oracle")
 ORACLE_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+ORACLE_FAST_PATH = os.path.join(ORACLE_DIR, "liboracle_fast.so")  # the same source without its work counters, -O3: bench.py's cpu_baseline
 
 _P = C.POINTER
 _vp = C.c_void_p
@@ -57,22 +58,32 @@ _SIGS = {
 }
 
 _lib = None
+_fast = None
 
 
 def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 
 
-def load():
-    global _lib
+def _open(path):
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def load(fast=False):
+    """liboracle.so (the checker, counting its work) or, fast=True, liboracle_fast.so (un-instrumented, for timing)."""
+    global _lib, _fast
+    if fast:
+        if _fast is None:
+            _fast = _open(ORACLE_FAST_PATH)
+        return _fast
     if _lib is None:
-        if not os.path.exists(ORACLE_PATH):
-            build()
-        lib = C.CDLL(ORACLE_PATH)
-        for name, (res, args) in _SIGS.items():
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
-        _lib = lib
+        _lib = _open(ORACLE_PATH)
     return _lib
 
 
@@ -87,8 +98,8 @@ def f64(a):
 class OracleScene:
     """Owns an orc_scene built from a raymond_amd.scene.Scene."""
 
-    def __init__(self, scene):
-        self.lib = load()
+    def __init__(self, scene, fast=False):
+        self.lib = load(fast)
         objs, n, descs, ng, keep = scene.flatten()
         self._keep = (objs, descs, keep)
         self.handle = self.lib.orc_scene_create(objs, n, descs, ng)

@@ -96,10 +96,11 @@ def test_cpp_render_tiled_equals_python_path(cli, gpu_ctx, tmp_path, scene, spi)
     render.render_tiles(gpu_ctx, ds, st.camera_settings, st, generate_tiles(W, H, (32, 32)), fb)
     img_py = fb.download() / float(spp)
     assert img_cpp.tobytes() == img_py.tobytes()
-    # tone-mapped PPM == the library's resolve kernel wherever both are defined the same way (host libm vs ocml pow/exp: +-1 level)
+    # tone-mapped PPM (host libm) == the library's resolve stage, byte for byte (pixels an ulp of the device's exp / pow could decide are
+    # recomputed on the host: rmd_resolve_tonemap)
     with open(ppm, "rb") as f:
         assert f.readline() == b"P6\n" and f.readline() == b"%d %d\n" % (W, H) and f.readline() == b"255\n"
         host8 = np.frombuffer(f.read(), dtype=np.uint8).reshape(H, W, 3)
     dev8 = render.resolve_tonemap(gpu_ctx, fb, spp)
-    assert np.abs(host8.astype(int) - dev8.astype(int)).max() <= 1
+    assert np.array_equal(host8, dev8)
     fb.close(), ds.close()

@@ -310,3 +310,17 @@ def test_statistical_match_with_reference_png(oracle):
         (c_ref, n_ref), (c_our, n_our) = centroid(ref), centroid(a)
         assert n_ref > 10 and abs(n_our - n_ref) <= 0.1 * n_ref
         assert np.abs(c_ref - c_our).max() < 0.5
+
+
+def test_uninstrumented_build_gives_the_same_frames(oracle):
+    """liboracle_fast.so — the source without its work counters at -O3, what bench.py times as `cpu_baseline` — renders the frames
+    liboracle.so does, bit for bit (spheres and mesh, thin lens included)."""
+    from raymond_amd import scenes
+    from raymond_amd.scene import Settings, generate_tiles
+
+    for sc, dof in ((scenes.reflective_spheres(), False), (scenes.gold_dragon_standin(n=10), True)):
+        st = Settings(scenes.camera(96, 64, aperture_radius=0.5 if dof else 0.0), sample_count=3, bounce_limit=5, seed=31, use_dof=dof)
+        tiles = generate_tiles(96, 64, (32, 32))
+        a = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=2)
+        b = oracle.OracleScene(sc, fast=True).render_tiles(st.camera_settings, st, tiles, threads=2)
+        assert a.tobytes() == b.tobytes() and a.any()

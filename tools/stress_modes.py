@@ -1,4 +1,4 @@
-"""The full C3 frame in every launch form (0 = persistent workgroups, 3 = one wave per work item) and several splits, N frames each: every
+"""The full C3 frame in every launch form (0 = persistent workgroups, 1 = one wave per work item) and several splits, N frames each: every
 frame must equal the first one bit for bit (work items are drawn in a different order on every run).  python tools/stress_modes.py [frames] [spp]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,9 +15,9 @@ with render.Context(0) as ctx:
     ds = render.DeviceScene(ctx, sc)
     fb = render.Framebuffer(ctx, cam.backbuffer_width, cam.backbuffer_height)
     want, bad = None, 0
-    for mode in (0, 3):
+    for mode in (0, 1):
         for split in (0, 2, 7):
-            ctx.set_tunable(abi.RMD_TUNE_GRID_MODE, mode), ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
+            ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, mode), ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
             for i in range(frames):
                 fb.zero()
                 render.render_tiles(ctx, ds, cam, st, tiles, fb)
