@@ -64,6 +64,36 @@ inline double rmin(double a, double b) { return std::fmin(a, b); }
 const double PI = 3.14159265358979323846; /* core/src/math.rs:19 */
 const double F_MAX = std::numeric_limits<double>::max(); /* core/src/math.rs:20 */
 
+/* ------------------------------------------------------------------ mutation switch (tools/mutation_pins.py)
+ * What does the reference's own render (examples/ReflectiveSpheres.png) pin?  Each value > 0 "repairs" ONE of the reference's quirks the
+ * way a well-meaning port would; the script renders the PNG's scene with each and reports which the statistical pin rejects
+ * (DESIGN.md section 2).  0 = the faithful restatement, the only value any test, smoke() or bench.py uses; liboracle_fast.so has no switch. */
+enum {
+	MUT_NONE = 0,
+	MUT_Q1_VIEW_FROM_RAY,        /* :256 view_dir = -ray.direction instead of normalize(camera - P) at every depth */
+	MUT_Q2_PDF_WITH_PI,          /* :399-401 pdf = sqrt(r1) / PI (the 1/PI the BRDF omits as well) */
+	MUT_Q2_UNIFORM_SAMPLER,      /* :396-406 cos(theta) = r1, pdf = 1/2: the uniform sampler the name promises (an unbiased alternative) */
+	MUT_Q3_GGX_ATAN,             /* :289 theta = atan(a * sqrt(r2 / (1 - r2))) */
+	MUT_Q4_A2_IS_ALPHA_SQUARED,  /* :363 a2 = roughness^4 */
+	MUT_Q4_K_DIRECT_LIGHTING,    /* :374 k = (r + 1)^2 / 8 */
+	MUT_Q4_NO_EPSILONS,          /* :312 without + 0.001, :316 without + 0.0001 */
+	MUT_Q4_CLAMPED_SPEC_COS,     /* :306 cos_theta = max(n.l, 0) in the specular branch */
+	MUT_PROB_D_ALL_DIFFUSE,      /* :263 prob_d = 1 - metalness: Diffuse materials get no specular lobe */
+	MUT_F0_ZERO,                 /* :257 F0 = lerp(0.0, colour, metalness) */
+	MUT_OFFSETS_1E3,             /* :269 / :300 ray offsets 1e-3 instead of 1e-5 / 1e-4 */
+	MUT_Q10_SPHERE_FAR_ROOT,     /* sphere.rs:21-24 origin inside: the far root instead of a miss */
+	MUT_Q11_TWO_SIDED_PLANES,    /* plane.rs:14 |denom| > 1e-6 */
+	MUT_Q14_ONE_MORE_SEGMENT,    /* :200 trace(.., 0): bounce_limit + 1 segments */
+	MUT_Q14_EMISSION_FRONT_ONLY, /* :250-252 emission only when the surface faces the ray */
+	MUT_COUNT
+};
+#ifdef ORC_NO_COUNTERS
+constexpr int g_mutation = MUT_NONE;
+#else
+int g_mutation = MUT_NONE;
+#endif
+inline bool mut(int k) { return g_mutation == k; }
+
 /* ------------------------------------------------------------------ work counters */
 struct Counters {
 	uint64_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -184,8 +214,12 @@ Hit sphere_intersects(const Sphere &s, const Ray &ray) {
 	V3 q = c - t * ray.direction;
 	double p = dot(q, q);
 	if (p > s.radius * s.radius) return hit_none();
-	t -= std::sqrt(s.radius * s.radius - p);
-	if (t <= 0.0) return hit_none();
+	const double half_chord = std::sqrt(s.radius * s.radius - p);
+	t -= half_chord;
+	if (t <= 0.0) {
+		if (mut(MUT_Q10_SPHERE_FAR_ROOT) && t + 2.0 * half_chord > 0.0) return hit_new(t + 2.0 * half_chord);
+		return hit_none();
+	}
 	return hit_new(t);
 }
 /* sphere.rs:31-35 */
@@ -197,7 +231,7 @@ V3 sphere_normal(const Sphere &s, const Ray &ray, double distance) {
 Hit plane_intersects(const Plane &pl, const Ray &ray) {
 	V3 normal = pl.normal;
 	double denom = dot(normal, -ray.direction);
-	if (denom > 1e-6) {
+	if (denom > 1e-6 || (mut(MUT_Q11_TWO_SIDED_PLANES) && denom < -1e-6)) {
 		V3 p0l0 = pl.origin - ray.origin;
 		double t = dot(p0l0, -normal) / denom;
 		if (t >= 0.0) return hit_new(t);
@@ -521,6 +555,7 @@ V3 lerp_vec(V3 mn, V3 mx, double a) { return v3(lerp(mn.x, mx.x, a), lerp(mn.y, 
  * unconditionally, and so does gcc for std::pow(x, 2.0) — written as a product here. */
 double ggx_distribution(V3 n, V3 h, double roughness) {
 	double a2 = roughness * roughness;
+	if (mut(MUT_Q4_A2_IS_ALPHA_SQUARED)) a2 = a2 * a2;
 	double NdotH = dot(n, h);
 	double nominator = a2;
 	double denominator = (NdotH * NdotH) * (a2 - 1.0) + 1.0;
@@ -531,6 +566,7 @@ double ggx_distribution(V3 n, V3 h, double roughness) {
 double geometry_schlick_ggx(V3 n, V3 v, double r) {
 	double numerator = rmax(dot(n, v), 0.0);
 	double k = (r * r) / 8.0;
+	if (mut(MUT_Q4_K_DIRECT_LIGHTING)) k = ((r + 1.0) * (r + 1.0)) / 8.0;
 	double denominator = numerator * (1.0 - k) + k;
 	return numerator / denominator;
 }
@@ -557,6 +593,8 @@ void uniform_sample_hemisphere(double r1, double r2, V3 &cartesian, double &pdf)
 	double theta = std::acos(std::sqrt(r1));
 	double phi = 2.0 * PI * r2;
 	pdf = std::sqrt(r1);
+	if (mut(MUT_Q2_PDF_WITH_PI)) pdf = pdf / PI;
+	if (mut(MUT_Q2_UNIFORM_SAMPLER)) theta = std::acos(r1), pdf = 0.5;
 	cartesian = v3(std::sin(theta) * std::cos(phi), std::cos(theta), std::sin(theta) * std::sin(phi));
 }
 /* :286-296 (Q3: theta = a*sqrt(r2/(1-r2)) used directly as an angle) */
@@ -564,6 +602,7 @@ V3 importance_sample_ggx(V3 reflect, double roughness, double r1, double r2) {
 	double a = roughness * roughness;
 	double phi = 2.0 * PI * r1;
 	double theta = a * std::sqrt(r2 / (1.0 - r2));
+	if (mut(MUT_Q3_GGX_ATAN)) theta = std::atan(theta);
 	V3 h = v3(std::sin(theta) * std::cos(phi), std::cos(theta), std::sin(theta) * std::sin(phi));
 	V3 tangent, bitangent;
 	create_coordinate_system_of_n(reflect, tangent, bitangent);
@@ -634,7 +673,10 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 	const Object &object = ctx.scene->objects[oi];
 	V3 normal = geometry_normal(object, ray, hit);                    /* :244-245 */
 	V3 fragment_position = ray.origin + ray.direction * hit.distance; /* :246 */
-	if (object.material.kind == RMD_MAT_EMISSION) return object.material.color; /* :250-252 */
+	if (object.material.kind == RMD_MAT_EMISSION) { /* :250-252 */
+		if (mut(MUT_Q14_EMISSION_FRONT_ONLY) && !(dot(normal, -ray.direction) > 0.0)) return v3(0.0, 0.0, 0.0);
+		return object.material.color;
+	}
 	V3 material_color = object.material.color;
 	double material_roughness = object.material.roughness;
 	double material_metalness = object.material.kind == RMD_MAT_METAL ? 1.0 : 0.0; /* :248-249 */
@@ -642,19 +684,23 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 
 	V3 cam_pos = v3(ctx.cam->position[0], ctx.cam->position[1], ctx.cam->position[2]);
 	V3 view_dir = normalize(cam_pos - fragment_position); /* :256 (Q1) */
+	if (mut(MUT_Q1_VIEW_FROM_RAY)) view_dir = -ray.direction;
 	V3 f0 = lerp_vec(v3(0.04, 0.04, 0.04), material_color, material_metalness); /* :257-258 */
+	if (mut(MUT_F0_ZERO)) f0 = lerp_vec(v3(0.0, 0.0, 0.0), material_color, material_metalness);
 	double r, r1, r2; /* :260, then :397-398 (diffuse) or :287-288 (specular): the depth's three draws come from one block */
 	rng.next3(r, r1, r2);
 	V3 lc_t, lc_b;
 	create_coordinate_system_of_n(normal, lc_t, lc_b); /* :261-262: Matrix3::from_cols(t, normal, b) */
 	double prob_d = lerp(0.5, 0.0, material_metalness); /* :263 */
+	if (mut(MUT_PROB_D_ALL_DIFFUSE)) prob_d = 1.0 - material_metalness;
+	const double off_d = mut(MUT_OFFSETS_1E3) ? 0.001 : 0.00001, off_s = mut(MUT_OFFSETS_1E3) ? 0.001 : 0.0001;
 	if (r < prob_d) {
 		/* :265-282 diffuse */
 		V3 sample;
 		double pdf;
 		uniform_sample_hemisphere(r1, r2, sample, pdf);
 		V3 sample_world = normalize(mat3_mul(lc_t, normal, lc_b, sample));
-		V3 radiance = trace(Ray{fragment_position + normal * 0.00001, sample_world}, ctx, rng, depth + 1);
+		V3 radiance = trace(Ray{fragment_position + normal * off_d, sample_world}, ctx, rng, depth + 1);
 		double cos_theta = rmax(dot(normal, sample_world), 0.0);
 		V3 halfway = normalize(sample_world + view_dir);
 		V3 fresnel = fresnel_schlick(rmax(dot(halfway, view_dir), 0.0), f0);
@@ -667,18 +713,19 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 		/* :283-319 specular */
 		V3 reflect = normalize(-view_dir - 2.0 * (-dot(view_dir, normal) * normal));
 		V3 sample_world = importance_sample_ggx(reflect, material_roughness, r1, r2);
-		V3 radiance = trace(Ray{fragment_position + normal * 0.0001, sample_world}, ctx, rng, depth + 1);
+		V3 radiance = trace(Ray{fragment_position + normal * off_s, sample_world}, ctx, rng, depth + 1);
 		double cos_theta = dot(normal, sample_world);
+		if (mut(MUT_Q4_CLAMPED_SPEC_COS)) cos_theta = rmax(cos_theta, 0.0);
 		V3 light_dir = normalize(sample_world);
 		V3 halfway = normalize(light_dir + view_dir);
 		V3 F = fresnel_schlick(dot(halfway, view_dir), f0);
 		double D = ggx_distribution(normal, halfway, material_roughness);
 		double G = geometry_smith(normal, view_dir, sample_world, material_roughness);
 		V3 nominator = D * G * F;
-		double denominator = 4.0 * dot(normal, view_dir) * cos_theta + 0.001;
+		double denominator = 4.0 * dot(normal, view_dir) * cos_theta + (mut(MUT_Q4_NO_EPSILONS) ? 0.0 : 0.001);
 		V3 specular = nominator / denominator;
 		V3 output = mul_ew(specular, radiance) * cos_theta;
-		double pdf = (D * dot(normal, halfway)) / (4.0 * dot(halfway, view_dir)) + 0.0001;
+		double pdf = (D * dot(normal, halfway)) / (4.0 * dot(halfway, view_dir)) + (mut(MUT_Q4_NO_EPSILONS) ? 0.0 : 0.0001);
 		return output / (1.0 - prob_d) / pdf;
 	}
 }
@@ -697,7 +744,7 @@ V3 sample_pixel(const Scene &scene, const rmd_camera &cam, const rmd_settings &s
 		primary = generate_primary_ray(x, y, cam, rng);
 	}
 	TraceContext ctx{&scene, &cam, st.bounce_limit, path_obj, path_sub, 0};
-	V3 out = trace(primary, ctx, rng, 1);
+	V3 out = trace(primary, ctx, rng, mut(MUT_Q14_ONE_MORE_SEGMENT) ? 0 : 1);
 	if (path_len) *path_len = ctx.path_len;
 	return out;
 }
@@ -1110,6 +1157,17 @@ void orc_resolve_tonemap(const double *accum, size_t n_pixels, double sample_cou
 		}
 		for (int c = 0; c < 3; c++) rgb8[i * 3 + c] = ok ? (uint8_t)v[c] : (uint8_t)0;
 	}
+}
+
+/* tools/mutation_pins.py only.  Returns the number of mutations, or -1 in the build that has none. */
+int32_t orc_set_mutation(int32_t k) {
+#ifdef ORC_NO_COUNTERS
+	(void)k;
+	return -1;
+#else
+	g_mutation = (k > 0 && k < MUT_COUNT) ? k : MUT_NONE;
+	return MUT_COUNT;
+#endif
 }
 
 void orc_walk_hist(uint64_t out[4 * 65 + 1]) {

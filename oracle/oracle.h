@@ -109,6 +109,8 @@ void orc_render_tiles(const orc_scene *s, const rmd_camera *cam, const rmd_setti
 /* Work counters summed over all threads since the last reset (feed the algorithmic-bytes figure):
  * [0] samples, [1] path segments (Scene::intersect calls), [2] grid cells visited, [3] triangle tests,
  * [4] mesh hits shaded (Triangle::get_surface_properties calls), [5] shaded bounces, [6] rng draws, [7] grid walks */
+/* Mutation switch of tools/mutation_pins.py (oracle.cpp: MUT_*): 0 = the faithful restatement.  No test, smoke() or bench.py sets it. */
+int32_t orc_set_mutation(int32_t k);
 void orc_counters_reset(void);
 /* per-walk histograms, buckets 0..63 and 64+ : cells visited, non-empty cells visited, triangle tests, max triangles per cell; [260] = walks that hit */
 void orc_walk_hist(uint64_t out[4 * 65 + 1]);

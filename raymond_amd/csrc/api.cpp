@@ -220,6 +220,22 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		d.roughness = o.material.roughness;
 		d.metalness = o.material.kind == RMD_MAT_METAL ? 1.0 : 0.0; // src/trace.rs:248-249
 	}
+	// pair_opposite_planes: plane j is tested together with the first earlier, still unpaired plane i whose normal is its exact negation
+	// (device_core.hpp: plane_pair_intersect — the facing conditions of such planes exclude each other, one division serves both)
+#ifndef RMD_PAIR_PLANES
+#define RMD_PAIR_PLANES 1
+#endif
+	for (uint32_t j = 0; j < n_objects && RMD_PAIR_PLANES; j++) {
+		if (hobj[j].geometry_kind != RMD_GEOM_PLANE) continue;
+		for (uint32_t i = 0; i < j; i++) {
+			if (hobj[i].geometry_kind != RMD_GEOM_PLANE || hobj[i].pair_info != 0u) continue;
+			bool opposite = true; // NaN components compare unequal: never paired
+			for (int a = 0; a < 3; a++) opposite = opposite && hobj[j].normal[a] == -hobj[i].normal[a];
+			if (!opposite) continue;
+			hobj[i].pair_info = rmd::kPairTestedAtPartner | j, hobj[j].pair_info = i + 1u;
+			break;
+		}
+	}
 	rmd_scene *sc = new (std::nothrow) rmd_scene();
 	if (!sc) return rmd::fail(ctx, RMD_ERR_OUT_OF_MEMORY, "rmd_scene_create: allocation failed");
 	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids;

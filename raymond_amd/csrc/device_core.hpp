@@ -187,6 +187,26 @@ RMD_DEV bool plane_intersect(V3 origin, V3 normal, V3 ro, V3 rd, double &t_out) 
 	}
 	return false;
 }
+// Two planes whose normals are exact negations of each other (the opposite walls of a box), tested together.  Plane::intersects
+// (plane.rs:11-24) is one-sided: a ray is tested further only against a plane it faces, `dot(normal, -rd) > 1e-6`.  With n_b = -n_a every
+// product and sum of the second denominator is the exact negation of the first's (round-to-nearest is symmetric), so
+// dot(n_b, -rd) = -dot(n_a, -rd) bit for bit (up to the sign of a zero, which no comparison here sees): the two facing conditions
+// exclude each other, and a lane's one division is num / |denom_a| with ITS plane's numerator — the operands and the IEEE division
+// plane.rs:17 performs for that plane.  One division sequence at full lane occupancy instead of two at about half each.
+// `first` tells which plane a hit belongs to.
+RMD_DEV bool plane_pair_intersect(V3 origin_a, V3 normal_a, V3 origin_b, V3 normal_b, V3 ro, V3 rd, double &t_out, bool &first) {
+	const double denom_a = dot(normal_a, -rd);
+	const bool faces_a = denom_a > 1e-6, faces_b = -denom_a > 1e-6; // = dot(normal_b, -rd) > 1e-6
+	const double num_a = dot(origin_a - ro, -normal_a), num_b = dot(origin_b - ro, -normal_b);
+	if (faces_a || faces_b) {
+		const double t = (faces_b ? num_b : num_a) / __builtin_fabs(denom_a);
+		if (t >= 0.0) {
+			t_out = t, first = faces_a;
+			return true;
+		}
+	}
+	return false;
+}
 // core/src/geometry/primitives/aabb.rs:10-31 (fmin/fmax = Rust f64::min/max NaN rule)
 RMD_DEV bool aabb_intersect(V3 bmin, V3 bmax, V3 ro, V3 rd, double &tmin_out) {
 	double ix = 1.0 / rd.x, iy = 1.0 / rd.y, iz = 1.0 / rd.z;

@@ -12,7 +12,8 @@ struct alignas(16) DevObject {
 	uint32_t geometry_kind; // RMD_GEOM_*
 	uint32_t grid_index;
 	uint32_t material_kind; // RMD_MAT_*
-	uint32_t _pad0;
+	uint32_t pair_info;     // planes only (rmd_scene_create: pair_opposite_planes): 0 = tested on its own; kPairTestedAtPartner | j = tested together
+	                        // with plane j > this index, at j's turn; i + 1 = tested here together with plane i < this index
 	double origin[3]; // plane origin / sphere centre
 	double radius;
 	double normal[3]; // plane normal
@@ -22,6 +23,7 @@ struct alignas(16) DevObject {
 	double _pad1[2];
 };
 static_assert(sizeof(DevObject) == 128, "DevObject layout");
+constexpr uint32_t kPairTestedAtPartner = 0x80000000u;
 
 // One AccGrid (reference core/src/geometry/acc_grid.rs:27-33), re-laid out at upload for the wave-cooperative walk
 // (grid_walk.hpp).  `cells[c] -> mapping_table[off] = count, idx...` (acc_grid.rs:67-74) becomes

@@ -41,6 +41,15 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 		uint32_t tri = 0;
 		bool hit = false;
 		if (o.geometry_kind == 0u) {
+			if (o.pair_info != 0u) { // a plane with an exactly opposite partner (device_core.hpp: plane_pair_intersect)
+				if (o.pair_info & kPairTestedAtPartner) continue; // at its partner's turn
+				const uint32_t e = o.pair_info - 1u;                 // the earlier partner, e < i
+				bool first = false;
+				if (want) hit = plane_pair_intersect(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, t, first);
+				// Scene::intersect's scan keeps the lexicographic minimum of (distance, index); objects between e and i have had their turn
+				if (want && hit && lex_less(t, first ? (int)e : (int)i, closest, best)) closest = t, best = first ? (int)e : (int)i, sub = 0u;
+				continue;
+			}
 			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
 		} else if (o.geometry_kind == 1u) {
 			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);

@@ -22,6 +22,14 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 		double t; // set by a hit and only read after one
 		bool hit = false;
 		if (o.geometry_kind == 0u) {
+			if (o.pair_info != 0u) { // a plane with an exactly opposite partner (device_core.hpp: plane_pair_intersect), tested at the later one's turn
+				if (o.pair_info & kPairTestedAtPartner) continue;
+				const uint32_t e = o.pair_info - 1u;
+				bool first = false;
+				if (want) hit = plane_pair_intersect(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, t, first);
+				if (want && hit && lex_less(t, first ? (int)e : (int)i, closest, best)) closest = t, best = first ? (int)e : (int)i;
+				continue;
+			}
 			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
 		} else if (o.geometry_kind == 1u) {
 			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);

@@ -318,6 +318,36 @@ def test_planes_special_rays_bit_exact(gpu_ctx, oracle):
     assert len(set(oobj.tolist())) >= 8 and (oobj[:64] >= 0).all()
 
 
+def test_paired_planes_keep_the_scan_order_on_ties(gpu_ctx, oracle):
+    """Planes with exactly opposite normals are tested together, at the later one's turn (plane_pair_intersect).  Scene::intersect's scan
+    (core/src/scene.rs:54-74, strict `<`) keeps the FIRST object among equal distances, so the merge must be lexicographic in (distance,
+    index): coincident planes before, between and after the partners of a pair — equal distances bit for bit — and the winner is the oracle's."""
+    from raymond_amd.scene import Material, Object, Plane, Scene, Sphere
+
+    sc = Scene()
+    grey = Material.Diffuse((0.5, 0.5, 0.5), 0.5)
+    for origin, normal in (
+        ((0.0, -1.0, 0.0), (0.0, 1.0, 0.0)),   # 0 floor, paired with 3
+        ((3.0, -1.0, 1.0), (0.0, 2.0, 0.0)),   # 1 the same plane, normal x 2 (same quotient bit for bit), no partner: between 0 and 3
+        ((0.0, 2.0, 0.0), (0.0, -2.0, 0.0)),   # 2 the ceiling's plane, no partner, before the ceiling
+        ((1.0, 2.0, -1.0), (0.0, -1.0, 0.0)),  # 3 ceiling, paired with 0
+        ((5.0, -1.0, 5.0), (0.0, 1.0, 0.0)),   # 4 floor again, paired with 5
+        ((0.0, 2.0, 0.0), (0.0, -1.0, 0.0)),   # 5 ceiling again
+        ((-2.0, 0.0, 0.0), (1.0, 0.0, 0.0)), ((2.0, 0.0, 0.0), (-1.0, 0.0, 0.0)),  # 6, 7 walls, paired
+        ((0.0, 0.0, 5.0), (0.0, 0.0, -1.0)),   # 8 back wall, no partner
+    ):
+        sc.objects.append(Object(Plane(origin, normal), grey))
+    sc.objects.append(Object(Sphere((0.3, 0.2, 2.0), 0.4), grey))
+    rng = np.random.default_rng(22)
+    rays = rays_toward(rng, 2 * N, (0, 0.5, 1.5), 2.5)
+    dobj, dt, dsub = probe.scene_intersect(gpu_ctx, render.DeviceScene(gpu_ctx, sc), rays)
+    oobj, ot, osub = oracle.OracleScene(sc).scene_intersect(rays)
+    assert np.array_equal(dobj, oobj)
+    m = oobj >= 0
+    assert np.array_equal(dt[m].view(np.uint64), ot[m].view(np.uint64))
+    assert (oobj == 0).sum() > 50 and (oobj == 2).sum() > 50 and not np.isin(oobj, (1, 3, 4, 5)).any()  # the ties went to the first plane
+
+
 def test_grid_walk(gpu_ctx, oracle, small_mesh_scene):
     """AccGrid::intersects incl. origins inside the box, on the max side (Q6) and axis-parallel rays (Q8)."""
     sc = small_mesh_scene

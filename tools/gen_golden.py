@@ -251,6 +251,11 @@ def png_blocks():
     assert img.shape == (340, 592, 3)
     blocks = img[:336].reshape(42, 8, 74, 8, 3).mean(axis=(1, 3))
     np.save(os.path.join(GOLD, "png_blocks.npy"), blocks.astype(np.float32))
+    # the reference's render of cli_old's scene (examples/GoldDragon.png, README.md:27): its dragon-free regions pin the room, the emitter,
+    # the camera and the red sphere of cli_old/src/main.rs:45-141 (tests/png_pin.py: run_room_checks)
+    img = read_png_rgb("/root/reference/examples/GoldDragon.png").astype(np.float64)
+    assert img.shape == (340, 592, 3)
+    np.save(os.path.join(GOLD, "png_blocks_dragon.npy"), img[:336].reshape(42, 8, 74, 8, 3).mean(axis=(1, 3)).astype(np.float32))
 
 
 if __name__ == "__main__":

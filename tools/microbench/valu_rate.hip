@@ -30,6 +30,11 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int n, uint32_t seed) {
 			if (OP == 15) d[i] = (d[i] < 2.0) ? d[i] + 1.0 : 1.0;             // v_cmp_lt_f64 + add + 2 cndmask
 			if (OP == 16) d[i] = d[i] / 1.0000001;                            // full IEEE division
 			if (OP == 17) d[i] = __builtin_sqrt(d[i]) + 1.0;                  // full IEEE sqrt + add
+			if (OP == 18) a[i] = __builtin_amdgcn_mul_u24(a[i], 0x51F53u) + 1u; // v_mul_u32_u24 (+add; or one v_mad_u32_u24)
+			if (OP == 19) a[i] = __builtin_amdgcn_mulhi_u24(a[i], 0x51F53u) + a[i]; // v_mul_hi_u32_u24 + add
+			if (OP == 20) d[i] = (double)(uint32_t)a[i] * 1.0000001, a[i] = (uint32_t)d[i]; // v_cvt_f64_u32 + mul + v_cvt_u32_f64
+			if (OP == 21) a[i] = (a[i] ^ 0x9E3779B9u ^ (uint32_t)it) + 1u;     // v_xor3 + add
+			if (OP == 22) d[i] = __builtin_fabs(d[i] - 1.5) < 0.25 ? 1.0 : d[i] * 1.0000001; // sub-free: cmp with modifiers + mul + 2 cndmask
 		}
 	}
 	uint32_t r = 0;
@@ -76,5 +81,10 @@ int main() {
 	run<15>("cmp_lt_f64 + add + 2 cndmask", 4);
 	run<16>("IEEE f64 division", 13);
 	run<17>("IEEE f64 sqrt + add", 20);
+	run<18>("v_mul_u32_u24 + add (or v_mad_u32_u24)", 2);
+	run<19>("v_mul_hi_u32_u24 + add", 2);
+	run<20>("cvt_f64_u32 + mul_f64 + cvt_u32_f64", 3);
+	run<21>("v_xor3 + add", 2);
+	run<22>("add + cmp + mul + 2 cndmask", 5);
 	return 0;
 }
