@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int n, uint32_t seed) {
 			if (OP == 15) d[i] = (d[i] < 2.0) ? d[i] + 1.0 : 1.0;             // v_cmp_lt_f64 + add + 2 cndmask
 			if (OP == 16) d[i] = d[i] / 1.0000001;                            // full IEEE division
 			if (OP == 17) d[i] = __builtin_sqrt(d[i]) + 1.0;                  // full IEEE sqrt + add
-			if (OP == 18) a[i] = __builtin_amdgcn_mul_u24(a[i], 0x51F53u) + 1u; // v_mul_u32_u24 (+add; or one v_mad_u32_u24)
-			if (OP == 19) a[i] = __builtin_amdgcn_mulhi_u24(a[i], 0x51F53u) + a[i]; // v_mul_hi_u32_u24 + add
+			if (OP == 18) a[i] = __umul24(a[i], 0x51F53u) + 1u; // v_mul_u32_u24 (+add; or one v_mad_u32_u24)
+			if (OP == 19) { uint32_t h; asm volatile("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(h) : "v"(a[i]), "v"(0x51F53u)); a[i] = h + a[i]; } // v_mul_hi_u32_u24 + add
 			if (OP == 20) d[i] = (double)(uint32_t)a[i] * 1.0000001, a[i] = (uint32_t)d[i]; // v_cvt_f64_u32 + mul + v_cvt_u32_f64
 			if (OP == 21) a[i] = (a[i] ^ 0x9E3779B9u ^ (uint32_t)it) + 1u;     // v_xor3 + add
 			if (OP == 22) d[i] = __builtin_fabs(d[i] - 1.5) < 0.25 ? 1.0 : d[i] * 1.0000001; // sub-free: cmp with modifiers + mul + 2 cndmask
