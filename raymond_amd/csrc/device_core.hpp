@@ -8,6 +8,13 @@
 #include "device_types.hpp"
 
 #define RMD_DEV __device__ __forceinline__
+// measured micro-optimisations, each bit-exact; the switches exist for tools/ab_multi.sh
+#ifndef RMD_OPT_BITOP3
+#define RMD_OPT_BITOP3 1
+#endif
+#ifndef RMD_OPT_SHARED_SQRT
+#define RMD_OPT_SHARED_SQRT 1
+#endif
 // Pointers read out of structs in memory are generic-address-space to the compiler, which then emits flat_load +
 // full waits; these casts state that they point to global memory (HBM), giving global_load and counted waits.
 #define RMD_GLOBAL __attribute__((address_space(1)))
@@ -123,7 +130,12 @@ RMD_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 		const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2; // one 32x32->64 multiply each (v_mad_u64_u32)
 		const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
 		const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+		// a ^ b ^ c in one instruction: gfx950's v_bitop3_b32 with the truth table of a three-way XOR (the compiler emits two v_xor_b32)
+#if RMD_OPT_BITOP3
+		uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+#else
 		uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+#endif
 		c0 = n0, c1 = lo1, c2 = n2, c3 = lo0;
 		k0 += W0, k1 += W1;
 	}
@@ -456,18 +468,25 @@ RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const 
 		diffuse = r < prob_d;                      // :264
 		double phi, st, ct, sp, cp;
 		V3 axis;
+		// both samplers begin with a square root — sqrt(r1) (:399) or sqrt(r2 / (1 - r2)) (:289): one sequence for the lanes of either kind
+#if RMD_OPT_SHARED_SQRT
+		double root_arg = r1;
+		if (!diffuse) root_arg = r2 / (1.0 - r2);
+		const double root = sqrt64(root_arg);
+#else
+		const double root = diffuse ? sqrt64(r1) : sqrt64(r2 / (1.0 - r2));
+#endif
 		if (diffuse) {
 			// uniform_sample_hemisphere (:396-406), frame around the normal (:261-262)
-			const double sr = sqrt64(r1);
-			hemisphere_sincos(sr, st, ct);
+			hemisphere_sincos(root, st, ct);
 			phi = 2.0 * kPi * r2;
-			pdf_d = sr;
+			pdf_d = root;
 			axis = normal;
 		} else {
 			// importance_sample_ggx (:286-296), frame around the mirror direction (:285)
 			const double a = in.roughness * in.roughness;
 			phi = 2.0 * kPi * r1;
-			sincos_cw(a * sqrt64(r2 / (1.0 - r2)), st, ct);
+			sincos_cw(a * root, st, ct);
 			axis = normalize(-view - 2.0 * (-dot(view, normal) * normal));
 		}
 		sincos_cw(phi, sp, cp);
