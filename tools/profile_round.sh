@@ -21,6 +21,7 @@ for wl in C3:500 C2:500; do
 done
 cd "$root"
 python3 tools/pmc_summary.py --json "$out" --tag "profiles/$name" "$out"/C3_500_sq "$out"/C3_500_fetch "$out"/C3_500_write "$out"/C2_500_sq "$out"/C2_500_fetch "$out"/C2_500_write > "$out/pmc_counters.txt"
+tools/kernel_regs.sh > "$out/kernel_regs.txt" 2>&1 || true  # registers / spills / scratch of every kernel of the library, from the compiler's metadata
 f=$(find "$out/trace" -name "*kernel_stats.csv" | head -1); cp "$f" "$out/kernel_stats.csv"
 f=$(find "$out/trace" -name "*kernel_trace.csv" | head -1); python3 tools/summarize_trace.py "$f" > "$out/render_kernel_dispatches.txt"
 # the un-profiled bench line, reading the traffic / VALU figures just collected
