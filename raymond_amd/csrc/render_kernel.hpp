@@ -13,6 +13,26 @@ namespace rmd {
 // LDS per wave: the cooperative-walk scratch, only when the scene has grids.
 // per-wave LDS of the grid kernel: the walk scratch and the 64 paths' throughput (3 doubles per lane)
 __host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) : 0; }
+// The shelf (split launches of grid scenes, RMD_TUNE_SHELF): a lane whose ray has to walk a grid puts that path on its shelf in LDS — ray,
+// closest plane / sphere hit so far, pool item, depth, RNG block; its throughput stays in the second of two throughput slots — and goes on
+// with another sample; the wave walks when (nearly) every lane has a ray on its shelf, so a walk starts with a full wave instead of the
+// ~38 rays a wave's own paths have waiting at any one time, and no lane idles through the trips until then.  Everything stays inside the
+// wave: no other wave is waited for (the CU-wide pool of tools/experiments/walk_pool.patch lost exactly there).
+struct ShelfWave { // one wave's shelves, structure of arrays over its lanes
+	double ray[6][64]; // ro.xyz, rd.xyz
+	double part_t[64]; // closest plane / sphere hit (after the walk: closest hit of all)
+	int32_t part_obj[64];
+	uint32_t part_sub[64];
+	uint32_t item[64];
+	uint32_t meta[64]; // depth | rng_block << 8
+};
+static_assert(sizeof(ShelfWave) == 4608, "shelf layout");
+__host__ __device__ inline size_t wave_lds_bytes_shelf() { return sizeof(WalkScratch) + 2u * 64u * 3u * sizeof(double) + sizeof(ShelfWave); }
+constexpr uint32_t kShelfWavesPerWg = 12; // 3 per SIMD: 12 x 9,984 bytes of wave LDS beside the occupancy masks fit the CU's 160 KB (16 do not)
+#ifndef RMD_SHELF_BATCH
+#define RMD_SHELF_BATCH 56
+#endif
+constexpr uint32_t kShelfBatch = RMD_SHELF_BATCH; // shelved rays that make the wave walk
 
 // Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
 // reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
@@ -103,10 +123,11 @@ enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
 // One wave's share of a launch: list mode — the 64 entries from `first`; tile modes — work item `first` = (wave tile, sample
 // sub-range).  Called by all 64 lanes of a wave in uniform control flow; lobjs / lds_masks / wave_lds are the workgroup's staged
 // object table and occupancy masks and this wave's scratch in LDS.
-template <int MODE, bool GRID>
+template <int MODE, bool GRID, bool SHELF = false>
 RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work,
                          double *__restrict__ out, int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub, const DevObject *lobjs,
                          const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first) {
+	static_assert(!SHELF || (GRID && MODE == kModeTilesBuffered), "the shelf serves split launches of grid scenes");
 	constexpr bool LIST = MODE == kModeList;
 	const uint32_t lane = threadIdx.x & 63u;
 	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
@@ -171,14 +192,20 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 	// the grid kernel (at its register limit: one component was living in scratch) keeps it in LDS behind the wave's walk scratch
 	V3 T_reg = mk(1.0, 1.0, 1.0);
 	[[maybe_unused]] double *T_lds = GRID ? reinterpret_cast<double *>(wave_lds + sizeof(WalkScratch)) + lane : nullptr;
+	[[maybe_unused]] uint32_t t_slot = 0; // SHELF: which of the lane's two throughput slots belongs to its active path (0 or 192 doubles on)
 	auto load_T = [&]() -> V3 {
-		if constexpr (GRID) return mk(T_lds[0], T_lds[64], T_lds[128]);
+		if constexpr (SHELF) return mk(T_lds[t_slot], T_lds[t_slot + 64u], T_lds[t_slot + 128u]);
+		else if constexpr (GRID) return mk(T_lds[0], T_lds[64], T_lds[128]);
 		else return T_reg;
 	};
 	auto store_T = [&](V3 v) {
-		if constexpr (GRID) T_lds[0] = v.x, T_lds[64] = v.y, T_lds[128] = v.z;
+		if constexpr (SHELF) T_lds[t_slot] = v.x, T_lds[t_slot + 64u] = v.y, T_lds[t_slot + 128u] = v.z;
+		else if constexpr (GRID) T_lds[0] = v.x, T_lds[64] = v.y, T_lds[128] = v.z;
 		else T_reg = v;
 	};
+	// SHELF: the lane's second path (see ShelfWave): 0 = none, 1 = waits for its walk, 2 = walked
+	[[maybe_unused]] uint32_t shelf = 0;
+	[[maybe_unused]] ShelfWave *sw = SHELF ? reinterpret_cast<ShelfWave *>(wave_lds + sizeof(WalkScratch) + 2u * 64u * 3u * sizeof(double)) : nullptr;
 	uint32_t path_len = 0;
 	// Every trip of the loop has two halves.  (B) each lane that needs a ray gets one — the bounce ray of the hit its last
 	// intersection found (`to_shade`), or the primary ray of the next sample when its path has ended (`need_sample`) — in ONE
@@ -245,6 +272,19 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 		// ---------------- (B) hand out samples, then rays
 		bool prim = false;
 		if constexpr (to_buffer) {
+			// SHELF: a lane whose path has ended first takes back the path on its shelf, if that has been walked: it goes on from the closest
+			// hit (classification below) — no ray to generate, nothing to intersect
+			if constexpr (SHELF) {
+				if (need_sample && shelf == 2u) {
+					ro = mk(sw->ray[0][lane], sw->ray[1][lane], sw->ray[2][lane]), rd = mk(sw->ray[3][lane], sw->ray[4][lane], sw->ray[5][lane]);
+					part_t = sw->part_t[lane], part_obj = sw->part_obj[lane], part_sub = sw->part_sub[lane];
+					item = sw->item[lane];
+					const uint32_t meta = sw->meta[lane];
+					depth = meta & 0xFFu, rng_block = meta >> 8;
+					t_slot ^= 192u, shelf = 0u;
+					need_sample = false, has_ray = true, new_ray = false, waiting = false;
+				}
+			}
 			// the next pool items go to the lanes whose path has ended
 			const unsigned long long idle = __ballot(need_sample);
 			if (idle != 0ull && next_item < pool_items) {
@@ -254,6 +294,7 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 					item = k, prim = true;
 			}
 			alive = prim || has_ray || to_shade;
+			if constexpr (SHELF) alive = alive || shelf != 0u;
 			if (__ballot(alive) == 0ull) {
 				if (next_item >= pool_items) break;
 				continue; // a handout that fell entirely on slots outside the tile

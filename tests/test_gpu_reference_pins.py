@@ -204,6 +204,28 @@ def dragon(product_lib):
     return scenes.gold_dragon_standin()
 
 
+def test_room_of_cli_old_matches_the_reference_render_on_the_gpu(gpu_ctx, oracle, dragon):
+    """examples/GoldDragon.png — the reference's render of cli_old/src/main.rs:45-150 — against the HIP path on the benchmark scene (C3's:
+    the 99,372-triangle stand-in in the dragon's place) at the PNG's 592x340 and 500 spp, in the regions the dragon neither covers nor
+    lights: ceiling, upper back wall, side walls, the red sphere's glossy glow on the left wall (tests/png_pin.py: run_room_checks, the
+    checks the oracle passes in tests/test_oracle_golden.py).  Two 250-sample halves give the noise yardstick."""
+    import png_pin
+
+    st = Settings(scenes.camera(592, 340), sample_count=500, tile_size=(32, 32), bounce_limit=5, seed=scenes.SEED)
+    cam = st.camera_settings
+    tiles = png_pin.room_tiles()
+    ds = render.DeviceScene(gpu_ctx, dragon)
+    fb = render.Framebuffer(gpu_ctx, 592, 340)
+    halves = []
+    for begin in (0, 250):
+        fb.zero()
+        render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb, begin, 250)
+        halves.append(fb.download())
+    fb.close(), ds.close()
+    failed = [(name, detail) for name, ok, detail in png_pin.run_room_checks(oracle, halves) if not ok]
+    assert not failed, failed
+
+
 def test_c4_shaped_launch(gpu_ctx, oracle, dragon):
     """3840x2160, 8 bounces on the 99,372-triangle stand-in (BASELINE.json configs[3]) through `rmd_render_tiles`, 16 spp:
     (a) 400 spot pixels — all 16 samples each — equal the oracle's sequential sums; (b) a scratch cap that forces the
