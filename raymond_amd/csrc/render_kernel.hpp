@@ -13,26 +13,6 @@ namespace rmd {
 // LDS per wave: the cooperative-walk scratch, only when the scene has grids.
 // per-wave LDS of the grid kernel: the walk scratch and the 64 paths' throughput (3 doubles per lane)
 __host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) : 0; }
-// The shelf (split launches of grid scenes, RMD_TUNE_SHELF): a lane whose ray has to walk a grid puts that path on its shelf in LDS — ray,
-// closest plane / sphere hit so far, pool item, depth, RNG block; its throughput stays in the second of two throughput slots — and goes on
-// with another sample; the wave walks when (nearly) every lane has a ray on its shelf, so a walk starts with a full wave instead of the
-// ~38 rays a wave's own paths have waiting at any one time, and no lane idles through the trips until then.  Everything stays inside the
-// wave: no other wave is waited for (the CU-wide pool of tools/experiments/walk_pool.patch lost exactly there).
-struct ShelfWave { // one wave's shelves, structure of arrays over its lanes
-	double ray[6][64]; // ro.xyz, rd.xyz
-	double part_t[64]; // closest plane / sphere hit (after the walk: closest hit of all)
-	int32_t part_obj[64];
-	uint32_t part_sub[64];
-	uint32_t item[64];
-	uint32_t meta[64]; // depth | rng_block << 8
-};
-static_assert(sizeof(ShelfWave) == 4608, "shelf layout");
-__host__ __device__ inline size_t wave_lds_bytes_shelf() { return sizeof(WalkScratch) + 2u * 64u * 3u * sizeof(double) + sizeof(ShelfWave); }
-constexpr uint32_t kShelfWavesPerWg = 12; // 3 per SIMD: 12 x 9,984 bytes of wave LDS beside the occupancy masks fit the CU's 160 KB (16 do not)
-#ifndef RMD_SHELF_BATCH
-#define RMD_SHELF_BATCH 56
-#endif
-constexpr uint32_t kShelfBatch = RMD_SHELF_BATCH; // shelved rays that make the wave walk
 
 // Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
 // reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
@@ -123,11 +103,10 @@ enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
 // One wave's share of a launch: list mode — the 64 entries from `first`; tile modes — work item `first` = (wave tile, sample
 // sub-range).  Called by all 64 lanes of a wave in uniform control flow; lobjs / lds_masks / wave_lds are the workgroup's staged
 // object table and occupancy masks and this wave's scratch in LDS.
-template <int MODE, bool GRID, bool SHELF = false>
+template <int MODE, bool GRID>
 RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work,
                          double *__restrict__ out, int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub, const DevObject *lobjs,
                          const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first) {
-	static_assert(!SHELF || (GRID && MODE == kModeTilesBuffered), "the shelf serves split launches of grid scenes");
 	constexpr bool LIST = MODE == kModeList;
 	const uint32_t lane = threadIdx.x & 63u;
 	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
@@ -192,20 +171,14 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 	// the grid kernel (at its register limit: one component was living in scratch) keeps it in LDS behind the wave's walk scratch
 	V3 T_reg = mk(1.0, 1.0, 1.0);
 	[[maybe_unused]] double *T_lds = GRID ? reinterpret_cast<double *>(wave_lds + sizeof(WalkScratch)) + lane : nullptr;
-	[[maybe_unused]] uint32_t t_slot = 0; // SHELF: which of the lane's two throughput slots belongs to its active path (0 or 192 doubles on)
 	auto load_T = [&]() -> V3 {
-		if constexpr (SHELF) return mk(T_lds[t_slot], T_lds[t_slot + 64u], T_lds[t_slot + 128u]);
-		else if constexpr (GRID) return mk(T_lds[0], T_lds[64], T_lds[128]);
+		if constexpr (GRID) return mk(T_lds[0], T_lds[64], T_lds[128]);
 		else return T_reg;
 	};
 	auto store_T = [&](V3 v) {
-		if constexpr (SHELF) T_lds[t_slot] = v.x, T_lds[t_slot + 64u] = v.y, T_lds[t_slot + 128u] = v.z;
-		else if constexpr (GRID) T_lds[0] = v.x, T_lds[64] = v.y, T_lds[128] = v.z;
+		if constexpr (GRID) T_lds[0] = v.x, T_lds[64] = v.y, T_lds[128] = v.z;
 		else T_reg = v;
 	};
-	// SHELF: the lane's second path (see ShelfWave): 0 = none, 1 = waits for its walk, 2 = walked
-	[[maybe_unused]] uint32_t shelf = 0;
-	[[maybe_unused]] ShelfWave *sw = SHELF ? reinterpret_cast<ShelfWave *>(wave_lds + sizeof(WalkScratch) + 2u * 64u * 3u * sizeof(double)) : nullptr;
 	uint32_t path_len = 0;
 	// Every trip of the loop has two halves.  (B) each lane that needs a ray gets one — the bounce ray of the hit its last
 	// intersection found (`to_shade`), or the primary ray of the next sample when its path has ended (`need_sample`) — in ONE
@@ -228,6 +201,11 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 	int part_obj = -1;
 	uint32_t part_sub = 0;
 
+	// carried from a trip's intersection phase (A) and ray phase (B) to the next trip's classification (C)
+	bool complete = false, lens_failed = false, cut = false;
+	double t = 0.0;
+	uint32_t sub = 0;
+	int oi = -1;
 	// Wave-uniform main loop: all 64 lanes stay in it until every lane has finished its samples, so that finished
 	// lanes still lend their ALUs to the cooperative grid walk.  Per-lane work is predicated.
 #if RMD_DIAG
@@ -268,126 +246,9 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 			}
 		};
 		decltype(auto) Pt = trip_params();
-		RMD_TSTAMP(tt_class)
-		// ---------------- (B) hand out samples, then rays
-		bool prim = false;
-		if constexpr (to_buffer) {
-			// SHELF: a lane whose path has ended first takes back the path on its shelf, if that has been walked: it goes on from the closest
-			// hit (classification below) — no ray to generate, nothing to intersect
-			if constexpr (SHELF) {
-				if (need_sample && shelf == 2u) {
-					ro = mk(sw->ray[0][lane], sw->ray[1][lane], sw->ray[2][lane]), rd = mk(sw->ray[3][lane], sw->ray[4][lane], sw->ray[5][lane]);
-					part_t = sw->part_t[lane], part_obj = sw->part_obj[lane], part_sub = sw->part_sub[lane];
-					item = sw->item[lane];
-					const uint32_t meta = sw->meta[lane];
-					depth = meta & 0xFFu, rng_block = meta >> 8;
-					t_slot ^= 192u, shelf = 0u;
-					need_sample = false, has_ray = true, new_ray = false, waiting = false;
-				}
-			}
-			// the next pool items go to the lanes whose path has ended
-			const unsigned long long idle = __ballot(need_sample);
-			if (idle != 0ull && next_item < pool_items) {
-				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-				next_item += (uint32_t)__popcll(idle);
-				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) // slots outside a ragged tile are skipped
-					item = k, prim = true;
-			}
-			alive = prim || has_ray || to_shade;
-			if constexpr (SHELF) alive = alive || shelf != 0u;
-			if (__ballot(alive) == 0ull) {
-				if (next_item >= pool_items) break;
-				continue; // a handout that fell entirely on slots outside the tile
-			}
-		} else {
-			if (need_sample) {
-				if (s != s_end) prim = true; // src/trace.rs:199 — primary ray of sample s
-				else alive = false;
-			}
-			if (__ballot(alive) == 0ull) break;
-		}
-		if (prim) {
-			need_sample = false;
-			rng_block = 0;
-			depth = 1;
-			has_ray = true, new_ray = true;
-		}
-		// pixel and sample of the lane's path: in a split launch they are functions of the pool item (one integer of state per
-		// lane; kept as x, y, s they were spilled to scratch at every hand-out), otherwise the lane's own
-		if constexpr (to_buffer) {
-			x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
-			s = Pt.sample_begin + pool_first + (item >> 6);
-		}
-		Rng rng;
-		rng.pixel = y * Pt.W + x, rng.sample = s, rng.block = rng_block;
-		bool lens_failed = false;
-		if (Pt.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
-			if (prim) {
-				store_T(mk(1.0, 1.0, 1.0));
-				lens_failed = !primary_ray_dof(Pt, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
-			}
-			prim = false;
-		}
-		// the shading inputs of the hit a lane carries — evaluated for every lane, used by next_ray for the lanes that shade (a lane
-		// without a hit reads object 0 and whatever its slots hold: cheaper than nine register moves of stand-in values per trip)
-		NextRayShadeIn hit;
-		if constexpr (GRID) hit_normal = mk(parked[0], parked[64], parked[128]), hit_t = parked[192], hit_obj = parked_obj[0];
-		{
-			const DevObject &o = lobjs[to_shade ? hit_obj : 0];
-			hit.normal = hit_normal;
-			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
-			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
-		}
-		if constexpr (GRID) {
-			V3 T = mk(1.0, 1.0, 1.0);
-			if (to_shade) T = load_T();
-			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
-			if (to_shade || prim) store_T(T);
-		} else {
-			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
-		}
-		rng_block = rng.block;
-		bool cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
-		if (to_shade) {
-			depth++;
-			to_shade = false;
-			if (depth > Pt.bounce_limit) cut = true, has_ray = false;
-			else has_ray = true, new_ray = true;
-		}
-#if RMD_DIAG
-		if ((Pt.debug_flags & 8u) && Pt.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
-			const unsigned long long am = __ballot(alive), wm = __ballot(has_ray && !lens_failed);
-			if (lane == 0) atomicAdd(&Pt.debug_counters[10], 1ull), atomicAdd(&Pt.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&Pt.debug_counters[12], (unsigned long long)__popcll(wm));
-		}
-#endif
-		RMD_TSTAMP(tt_b)
-		// ---------------- (A) src/trace.rs:239 — closest hit of every lane that has a ray
-		const bool want = has_ray && !lens_failed;
-		double t;
-		uint32_t sub;
-		int oi;
-		bool complete; // lanes whose closest hit is known on this trip
-		if constexpr (GRID) {
-			if (want && new_ray) {
-				waiting = intersect_simple(objs, Pt.n_objects, grids, true, ro, rd, part_t, part_obj);
-				part_sub = 0u, new_ray = false;
-			}
-			RMD_TSTAMP(tt_simple)
-			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
-			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
-			trips_since_walk++;
-			if (wm != 0ull && ((uint32_t)__popcll(wm) >= Pt.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
-				trips_since_walk = 0;
-				intersect_grids(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters);
-				waiting = false;
-			}
-			RMD_TSTAMP(tt_walk)
-			complete = want && !waiting;
-			t = part_t, oi = part_obj, sub = part_sub;
-		} else {
-			oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, Pt.debug_flags, Pt.debug_counters);
-			complete = want;
-		}
+		// ---------------- (C) the hits the previous trip found (`complete`): miss, emission, or a surface to shade.  The loop is entered here: a
+		// trip is (C) classification -> (B) hand-out and next rays -> (A) intersection; a surface classified here is shaded a few lines
+		// further down, with nothing but the hand-out in between (the mesh kernel: two spilled registers instead of four).
 		bool terminal = lens_failed || cut;
 		V3 L = mk(0.0, 0.0, 0.0);
 		if (complete) {
@@ -454,6 +315,108 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 			}
 			has_ray = false;
 			need_sample = true;
+		}
+		RMD_TSTAMP(tt_class)
+		// ---------------- (B) hand out samples, then rays
+		bool prim = false;
+		if constexpr (to_buffer) {
+			// the next pool items go to the lanes whose path has ended
+			const unsigned long long idle = __ballot(need_sample);
+			if (idle != 0ull && next_item < pool_items) {
+				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+				next_item += (uint32_t)__popcll(idle);
+				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) // slots outside a ragged tile are skipped
+					item = k, prim = true;
+			}
+			alive = prim || has_ray || to_shade;
+			if (__ballot(alive) == 0ull) {
+				if (next_item >= pool_items) break;
+				continue; // a handout that fell entirely on slots outside the tile
+			}
+		} else {
+			if (need_sample) {
+				if (s != s_end) prim = true; // src/trace.rs:199 — primary ray of sample s
+				else alive = false;
+			}
+			if (__ballot(alive) == 0ull) break;
+		}
+		if (prim) {
+			need_sample = false;
+			rng_block = 0;
+			depth = 1;
+			has_ray = true, new_ray = true;
+		}
+		// pixel and sample of the lane's path: in a split launch they are functions of the pool item (one integer of state per
+		// lane; kept as x, y, s they were spilled to scratch at every hand-out), otherwise the lane's own
+		if constexpr (to_buffer) {
+			x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
+			s = Pt.sample_begin + pool_first + (item >> 6);
+		}
+		Rng rng;
+		rng.pixel = y * Pt.W + x, rng.sample = s, rng.block = rng_block;
+		lens_failed = false;
+		if (Pt.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
+			if (prim) {
+				store_T(mk(1.0, 1.0, 1.0));
+				lens_failed = !primary_ray_dof(Pt, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
+			}
+			prim = false;
+		}
+		// the shading inputs of the hit a lane carries — evaluated for every lane, used by next_ray for the lanes that shade (a lane
+		// without a hit reads object 0 and whatever its slots hold: cheaper than nine register moves of stand-in values per trip)
+		NextRayShadeIn hit;
+		if constexpr (GRID) hit_normal = mk(parked[0], parked[64], parked[128]), hit_t = parked[192], hit_obj = parked_obj[0];
+		{
+			const DevObject &o = lobjs[to_shade ? hit_obj : 0];
+			hit.normal = hit_normal;
+			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
+			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
+		}
+		if constexpr (GRID) {
+			V3 T = mk(1.0, 1.0, 1.0);
+			if (to_shade) T = load_T();
+			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
+			if (to_shade || prim) store_T(T);
+		} else {
+			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
+		}
+		rng_block = rng.block;
+		cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
+		if (to_shade) {
+			depth++;
+			to_shade = false;
+			if (depth > Pt.bounce_limit) cut = true, has_ray = false;
+			else has_ray = true, new_ray = true;
+		}
+#if RMD_DIAG
+		if ((Pt.debug_flags & 8u) && Pt.debug_counters) { // main-loop occupancy: trips, live lanes, lanes with a ray
+			const unsigned long long am = __ballot(alive), wm = __ballot(has_ray && !lens_failed);
+			if (lane == 0) atomicAdd(&Pt.debug_counters[10], 1ull), atomicAdd(&Pt.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&Pt.debug_counters[12], (unsigned long long)__popcll(wm));
+		}
+#endif
+		RMD_TSTAMP(tt_b)
+		// ---------------- (A) src/trace.rs:239 — closest hit of every lane that has a ray
+		const bool want = has_ray && !lens_failed;
+		if constexpr (GRID) {
+			if (want && new_ray) {
+				waiting = intersect_simple(objs, Pt.n_objects, grids, true, ro, rd, part_t, part_obj);
+				part_sub = 0u, new_ray = false;
+			}
+			RMD_TSTAMP(tt_simple)
+			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
+			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
+			trips_since_walk++;
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= Pt.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
+				trips_since_walk = 0;
+				intersect_grids(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters);
+				waiting = false;
+			}
+			RMD_TSTAMP(tt_walk)
+			complete = want && !waiting;
+			t = part_t, oi = part_obj, sub = part_sub;
+		} else {
+			oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, Pt.debug_flags, Pt.debug_counters);
+			complete = want;
 		}
 	}
 
