@@ -103,10 +103,11 @@ enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
 // One wave's share of a launch: list mode — the 64 entries from `first`; tile modes — work item `first` = (wave tile, sample
 // sub-range).  Called by all 64 lanes of a wave in uniform control flow; lobjs / lds_masks / wave_lds are the workgroup's staged
 // object table and occupancy masks and this wave's scratch in LDS.
+typedef const __attribute__((address_space(4))) unsigned long long *KernargWords; // the kernel-argument segment, as 8-byte words
 template <int MODE, bool GRID>
-RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work,
-                         double *__restrict__ out, int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub, const DevObject *lobjs,
-                         const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first) {
+RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids,
+                         const void *__restrict__ work, double *__restrict__ out, int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub,
+                         const DevObject *lobjs, const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first) {
 	constexpr bool LIST = MODE == kModeList;
 	const uint32_t lane = threadIdx.x & 63u;
 	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
@@ -229,18 +230,17 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 		// C2).  The empty asm keeps the compiler from hoisting the loads out of the loop.
 		auto trip_params = [&]() -> decltype(auto) {
 			if constexpr (RMD_TRIP_RELOAD) {
-				typedef const __attribute__((address_space(4))) unsigned long long *WordsInConstant;
-				// RenderParams is render_kernel's first argument: offset 0 of the kernel-argument segment
-				WordsInConstant src = (WordsInConstant)__builtin_amdgcn_kernarg_segment_ptr();
+				// `kernarg_params`: where the calling kernel's RenderParams argument lies in its kernel-argument segment (the kernel, which knows its
+				// own signature, passes it: KernargWords below)
+				KernargWords src = kernarg_params;
 				asm volatile("" : "+s"(src));
 				static_assert(sizeof(RenderParams) % 8 == 0, "copied in 8-byte words");
-				union {
-					RenderParams p;
-					unsigned long long w[sizeof(RenderParams) / 8];
-				} copy;
+				unsigned long long w[sizeof(RenderParams) / 8];
 #pragma unroll
-				for (unsigned i = 0; i < sizeof(RenderParams) / 8; i++) copy.w[i] = src[i];
-				return copy.p; // by value; only the fields a trip uses are loaded
+				for (unsigned i = 0; i < sizeof(RenderParams) / 8; i++) w[i] = src[i];
+				RenderParams copy;
+				__builtin_memcpy(&copy, w, sizeof(copy));
+				return copy; // by value; only the fields a trip uses are loaded
 			} else {
 				return (P);
 			}
@@ -301,14 +301,10 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
 				// sample's store travels alone, and a 24-byte store that straddles sectors was costing 2.7x its size in L2 write-backs
 				RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
-				// written through to memory (device scope) when a wave of this kernel adds the tile's samples (below): that wave may run on
-				// another XCD, whose L2 does not see this one's dirty lines
-				if (GRID || Pt.tile_done == nullptr) dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
-				else {
-					__hip_atomic_store(dst + 0, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store(dst + 1, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
+				// plain stores: when a wave of this kernel adds the tile's samples (below) — it may run on another XCD, whose L2 does not see this
+				// one's dirty lines — the release in front of the tile's counter writes them back, once per work item (round 2 wrote every
+				// sample through with three 8-byte agent-scope stores: 96 bytes at the memory side per 24-byte sample)
+				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
 			} else {
 				acc = acc + L; // src/trace.rs:203
 				s++;
@@ -430,10 +426,10 @@ RMD_DEV void render_wave(const RenderParams &P, const DevObject *__restrict__ ob
 	if constexpr (to_buffer && !GRID) { // (mesh scenes keep sum_kernel: api.cpp)
 		// The wave that finishes a wave tile's last sample range adds the tile's samples to the pixels, strictly in sample order
 		// (src/trace.rs:203: the reference's sequential sum, bit for bit) — inside this kernel, where the reads (bandwidth) overlap the
-		// other waves' arithmetic; as a kernel of its own the sum cost 5.5 ms per 1080p / 500 spp frame.  Release: this wave's sample
-		// stores are write-through and complete (vmcnt 0) before its count; acquire: the last wave invalidates its caches before it reads.
+		// other waves' arithmetic; as a kernel of its own the sum cost 5.5 ms per 1080p / 500 spp frame.  Release: an agent-scope fence
+		// writes this wave's sample stores back before its count; acquire: the last wave invalidates its caches before it reads.
 		if (P.tile_done != nullptr && wt < P.n_work) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's samples leave the XCD's L2 before its count is seen
 			uint32_t before = 0;
 			if (lane == 0u) before = __hip_atomic_fetch_add(P.tile_done + wt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
@@ -479,6 +475,9 @@ __global__ __launch_bounds__(PERSIST ? 64 * kPersistWavesPerWg : GRID ? 64 * kGr
     RenderParams P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work, double *__restrict__ out,
     int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub) {
 	extern __shared__ __align__(16) unsigned char smem[];
+	// P is this kernel's FIRST by-value argument: it starts at offset 0 of the kernel-argument segment, from where render_wave re-reads
+	// the launch parameters on every trip instead of carrying them in registers
+	const KernargWords kernarg_params = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr();
 	// LDS: [object table][grid occupancy masks][one walk scratch per wave]
 	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
 	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
@@ -506,11 +505,11 @@ __global__ __launch_bounds__(PERSIST ? 64 * kPersistWavesPerWg : GRID ? 64 * kGr
 			if ((tid & 63u) == 0u) item = atomicAdd(P.work_counter, 1u);
 			item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
 			if (item >= n_items) break;
-			render_wave<MODE, GRID>(P, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
+			render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
 		}
 	} else {
 		const uint32_t unit = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
-		render_wave<MODE, GRID>(P, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, MODE == kModeList ? unit * 64u : unit);
+		render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, MODE == kModeList ? unit * 64u : unit);
 	}
 }
 
