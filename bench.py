@@ -315,6 +315,8 @@ def main():
         rl = {
             "bound": "hbm", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "bytes_per_sample": bps, "avg_ms": round(avg_ms, 3),
+            "definition": "achieved / frac = ALGORITHMIC bytes per launch (SURVEY.md section 8d) / launch time; measured_gbs / measured_frac = L2<->fabric "
+                          "bytes by PMC (an upper bound on HBM bytes: Infinity-Cache hits included)",
         }
         if traffic is not None:
             rl["measured_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 3)
@@ -322,6 +324,7 @@ def main():
         if name == "C2":
             # the real bound of this workload: FP64 vector-ALU issue (the 8-object scene lives in LDS/SGPRs, HBM sees the framebuffer only)
             rl["note"] = "VALU-issue bound, not HBM bound: see `valu`"
+            rl["bound_by_counters"] = "valu"
             v = valu_block("C2", avg_ms) if spp == 500 else None
             if v:
                 rl["valu"] = v
@@ -342,6 +345,9 @@ def main():
             "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch" % rspp,
             "kernel": "rmd::render_kernel<1, true, true> + rmd::sum_kernel", "avg_ms": round(avg_ms, 3), "launch_ms": [round(v, 3) for v in rr["kernel_ms"]],
             "bytes_per_sample": round(bps, 2), "bytes_per_launch": bps * rr["samples_per_step"],
+            "definition": "achieved / frac = ALGORITHMIC bytes per launch / launch time — most of these bytes are answered by LDS (occupancy mask), L2 and the "
+                          "Infinity Cache; measured_gbs / measured_frac = L2<->fabric bytes by PMC, an upper bound on HBM bytes",
+            "bound_by_counters": "valu issue (see `valu`: ~0.85 of the issue slots busy at ~51 % lanes)",
             "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
             "how": "achieved = algorithmic bytes per launch (8 B x cells visited + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
                    "oracle counters in tests/golden/work_counters.json, + 24 B/pixel) / mean launch duration from HIP events on the launch stream; "
