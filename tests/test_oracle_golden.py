@@ -300,3 +300,28 @@ def test_uninstrumented_build_gives_the_same_frames(oracle):
         a = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=2)
         b = oracle.OracleScene(sc, fast=True).render_tiles(st.camera_settings, st, tiles, threads=2)
         assert a.tobytes() == b.tobytes() and a.any()
+
+
+def test_mutation_switch_is_off_by_default_and_changes_what_it_names(oracle):
+    """tools/mutation_pins.py's switch (oracle.cpp: MUT_*): every mutation but the behaviour-neutral ones changes a small frame, 0 restores
+    the faithful restatement bit for bit, and the un-instrumented build (what bench.py times) has no switch at all."""
+    L = oracle.load()
+    st = Settings(scenes.camera(64, 48), sample_count=4, bounce_limit=5, seed=3)
+    tiles = generate_tiles(64, 48, (32, 32))
+    sc = scenes.reflective_spheres()
+    base = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=2).tobytes()
+    n = L.orc_set_mutation(0)
+    assert n == 16
+    changed = []
+    try:
+        for k in range(1, n):
+            L.orc_set_mutation(k)
+            changed.append(oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=2).tobytes() != base)
+    finally:
+        L.orc_set_mutation(0)
+    assert oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=2).tobytes() == base
+    # clamped specular cosine (a sample below the surface carries no radiance in this closed room), far root inside a sphere, two-sided
+    # planes, front-only emission: no ray of this scene can tell
+    neutral_here = {8, 12, 13, 15}
+    assert [k for k in range(1, n) if not changed[k - 1]] == sorted(neutral_here)
+    assert oracle.load(fast=True).orc_set_mutation(3) == -1
