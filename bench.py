@@ -296,6 +296,7 @@ def main():
                 ", RCCL reduce(sum) of the f64 framebuffer to rank 0" + (" through rmd_reduce_framebuffer" if args.assemble == "abi" else "")) if world > 1 else ""),
             "rng": "philox4x32-10, key = seed, counter = (pixel, sample, block, 0); one block per consumer (jitter, lens round, shaded depth)",
             "seed": scenes.SEED,
+            "paths": "a path whose throughput has become exactly (0, 0, 0) is ended (rmd_settings.flags 0): every sample has the reference's value",
         },
     }
 
@@ -350,7 +351,8 @@ def main():
             "bound_by_counters": "valu issue (see `valu`: ~0.85 of the issue slots busy at ~51 % lanes)",
             "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
             "how": "achieved = algorithmic bytes per launch (8 B x cells visited + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
-                   "oracle counters in tests/golden/work_counters.json, + 24 B/pixel) / mean launch duration from HIP events on the launch stream; "
+                   "oracle counters in tests/golden/work_counters.json — of the work the default does: path segments behind a bounce weight of exactly "
+                   "zero are not counted, C3_reference holds the reference's full count — + 24 B/pixel) / mean launch duration from HIP events on the launch stream; "
                    "profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true> (persistent workgroups) + sum_kernel over the same launches",
         }
         if traffic is not None:

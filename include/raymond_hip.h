@@ -124,11 +124,17 @@ typedef struct rmd_camera {
  * RNG definition the reference lacks (it uses the unseedable thread_rng). */
 #define RMD_RENDER_DOF 1u /* rmd_settings.flags: primary rays through generate_primary_ray_with_dof (an extension: the
                              reference defines that function but its render loop never calls it) */
+#define RMD_RENDER_TRACE_BLACK_PATHS 2u /* rmd_settings.flags: keep tracing a path whose throughput has become exactly (0, 0, 0).  By default such a
+                             path is ended — its sample is exactly zero in the reference too, because trace() multiplies whatever the remaining
+                             segments find by that zero — with ONE difference: where a later vertex of such a path produces a non-finite radiance
+                             (the Heron normal of a degenerate mesh hit: ~1e-9 per sample on a 100k-triangle mesh; never in a scene of planes and
+                             spheres) the reference's sample is 0 x NaN = NaN and the default's is 0.  With this flag every sample is the
+                             reference's, NaN included, at the reference's cost (a quarter to a third more path segments in its scenes). */
 typedef struct rmd_settings {
 	uint32_t bounce_limit; /* Settings.bounce_limit; trace() starts at depth 1 (:200,:235) */
 	uint32_t sample_begin; /* first sample index s of this pass                             */
 	uint32_t sample_count; /* number of consecutive samples to add per pixel               */
-	uint32_t flags;        /* 0 = the reference's behaviour; RMD_RENDER_DOF                 */
+	uint32_t flags;        /* 0, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS                  */
 	uint64_t seed; /* Philox key; see "RNG" below                                   */
 } rmd_settings;
 

@@ -41,7 +41,7 @@ pub struct rmd_grid_desc {
 #[repr(C)]
 pub struct rmd_camera { pub backbuffer_width: u32, pub backbuffer_height: u32, pub fov_vert: f64, pub position: [f64; 3], pub focal_length: f64, pub aperture_radius: f64 }
 #[repr(C)]
-pub struct rmd_settings { pub bounce_limit: u32, pub sample_begin: u32, pub sample_count: u32, pub flags: u32 /* 0, or RMD_RENDER_DOF = 1 */, pub seed: u64 }
+pub struct rmd_settings { pub bounce_limit: u32, pub sample_begin: u32, pub sample_count: u32, pub flags: u32 /* 0, RMD_RENDER_DOF = 1, RMD_RENDER_TRACE_BLACK_PATHS = 2 */, pub seed: u64 }
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct rmd_tile_rect { pub left: u32, pub top: u32, pub width: u32, pub height: u32 }

@@ -104,11 +104,22 @@ Counters g_counters;
 thread_local Counters tl_counters;
 /* -DORC_NO_COUNTERS (liboracle_fast.so, the build bench.py times as cpu_baseline): the work counters and walk histograms compile to
  * nothing, so the timed loop is the reference's loop and not the reference's loop plus its instrumentation.  Same results bit for bit. */
+/* Work on a path whose bounce weights so far multiply to exactly zero can no longer reach the pixel (trace() multiplies whatever the rest
+ * of the path finds by that zero) and the product ends such a path (render_kernel.hpp; rmd_settings.flags RMD_RENDER_TRACE_BLACK_PATHS keeps
+ * it).  The oracle always traces it — it is the reference — but by default does not COUNT the work behind the zero, so that the counters are
+ * the work the product's default does: orc_count_black_paths(1) counts everything, as the reference executes it. */
+thread_local int tl_black = 0;
+int g_count_black_paths = 0;
 #ifdef ORC_NO_COUNTERS
 #define ORC_COUNT(k, n) ((void)0)
 #else
-#define ORC_COUNT(k, n) (tl_counters.c[k] += (n))
+#define ORC_COUNT(k, n) ((tl_black == 0 || g_count_black_paths) ? (void)(tl_counters.c[k] += (n)) : (void)0)
 #endif
+struct BlackScope { /* around trace()'s recursive call from a vertex whose weight is exactly zero */
+	bool on;
+	explicit BlackScope(bool b) : on(b) { if (on) tl_black++; }
+	~BlackScope() { if (on) tl_black--; }
+};
 /* per-walk histograms (design instrumentation): [kind][bucket], kind 0 = cells visited, 1 = non-empty cells visited, 2 = triangle tests, 3 = max triangles in one cell */
 std::atomic<uint64_t> g_walk_hist[4][65];
 std::atomic<uint64_t> g_walk_hits{0};
@@ -700,6 +711,16 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 		double pdf;
 		uniform_sample_hemisphere(r1, r2, sample, pdf);
 		V3 sample_world = normalize(mat3_mul(lc_t, normal, lc_b, sample));
+		bool black = false;
+#ifndef ORC_NO_COUNTERS
+		{ /* is this bounce's weight (:279-282) exactly zero?  (for the counters only: the values below are computed again, in the reference's place) */
+			V3 hw = normalize(sample_world + view_dir);
+			V3 fr = fresnel_schlick(rmax(dot(hw, view_dir), 0.0), f0);
+			V3 a = mul_ew((v3(1.0, 1.0, 1.0) - fr) * (1.0 - material_metalness), material_color);
+			black = (a.x == 0.0 && a.y == 0.0 && a.z == 0.0) || rmax(dot(normal, sample_world), 0.0) == 0.0;
+		}
+#endif
+		BlackScope scope(black);
 		V3 radiance = trace(Ray{fragment_position + normal * off_d, sample_world}, ctx, rng, depth + 1);
 		double cos_theta = rmax(dot(normal, sample_world), 0.0);
 		V3 halfway = normalize(sample_world + view_dir);
@@ -713,6 +734,17 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 		/* :283-319 specular */
 		V3 reflect = normalize(-view_dir - 2.0 * (-dot(view_dir, normal) * normal));
 		V3 sample_world = importance_sample_ggx(reflect, material_roughness, r1, r2);
+		bool black = false;
+#ifndef ORC_NO_COUNTERS
+		{ /* is this bounce's weight (:301-318) exactly zero?  D G F cos / pdf with G = Schlick-GGX(max(n.v, 0)) x Schlick-GGX(max(n.l, 0)) */
+			V3 hw = normalize(normalize(sample_world) + view_dir);
+			V3 fr = fresnel_schlick(dot(hw, view_dir), f0);
+			double n = ((((material_roughness * material_roughness) * rmax(dot(normal, view_dir), 0.0)) * rmax(dot(normal, sample_world), 0.0)) * dot(normal, sample_world)) *
+			           (4.0 * dot(hw, view_dir));
+			black = n == 0.0 || (fr.x == 0.0 && fr.y == 0.0 && fr.z == 0.0);
+		}
+#endif
+		BlackScope scope(black);
 		V3 radiance = trace(Ray{fragment_position + normal * off_s, sample_world}, ctx, rng, depth + 1);
 		double cos_theta = dot(normal, sample_world);
 		if (mut(MUT_Q4_CLAMPED_SPEC_COS)) cos_theta = rmax(cos_theta, 0.0);
@@ -1158,6 +1190,10 @@ void orc_resolve_tonemap(const double *accum, size_t n_pixels, double sample_cou
 		for (int c = 0; c < 3; c++) rgb8[i * 3 + c] = ok ? (uint8_t)v[c] : (uint8_t)0;
 	}
 }
+
+/* 1: the work counters include the segments behind a zero bounce weight (everything the reference executes); 0 (default): they stop there,
+ * like the product's default (see ORC_COUNT) */
+void orc_count_black_paths(int32_t on) { g_count_black_paths = on ? 1 : 0; }
 
 /* tools/mutation_pins.py only.  Returns the number of mutations, or -1 in the build that has none. */
 int32_t orc_set_mutation(int32_t k) {

@@ -111,6 +111,9 @@ void orc_render_tiles(const orc_scene *s, const rmd_camera *cam, const rmd_setti
  * [4] mesh hits shaded (Triangle::get_surface_properties calls), [5] shaded bounces, [6] rng draws, [7] grid walks */
 /* Mutation switch of tools/mutation_pins.py (oracle.cpp: MUT_*): 0 = the faithful restatement.  No test, smoke() or bench.py sets it. */
 int32_t orc_set_mutation(int32_t k);
+/* Whether the work counters include the path segments behind a bounce weight of exactly zero (0 = no, the default: the work the product's
+ * default does; 1 = yes: everything the reference executes).  Results never depend on it. */
+void orc_count_black_paths(int32_t on);
 void orc_counters_reset(void);
 /* per-walk histograms, buckets 0..63 and 64+ : cells visited, non-empty cells visited, triangle tests, max triangles per cell; [260] = walks that hit */
 void orc_walk_hist(uint64_t out[4 * 65 + 1]);

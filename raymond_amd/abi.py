@@ -36,6 +36,7 @@ RMD_MAT_DIFFUSE, RMD_MAT_METAL, RMD_MAT_EMISSION = 0, 1, 2
 
 RMD_MAX_BOUNCE_LIMIT = 16
 RMD_RENDER_DOF = 1  # rmd_settings.flags
+RMD_RENDER_TRACE_BLACK_PATHS = 2
 (RMD_TUNE_SAMPLE_SPLIT, RMD_TUNE_WALK_BATCH, RMD_TUNE_MASK_BUDGET, RMD_TUNE_LAUNCH_FORM, RMD_TUNE_SCRATCH_CAP_MB) = range(5)
 RMD_LAUNCH_AUTO, RMD_LAUNCH_PER_ITEM, RMD_LAUNCH_PERSISTENT = range(3)
 RMD_COMM_ID_BYTES = 128

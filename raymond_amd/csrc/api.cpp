@@ -161,6 +161,7 @@ RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const r
 	P.mask_words_total = scene ? scene->mask_words_total : 0;
 	P.key0 = (uint32_t)st->seed, P.key1 = (uint32_t)(st->seed >> 32);
 	P.use_dof = ((st->flags & RMD_RENDER_DOF) && cam->aperture_radius > 0.0) ? 1u : 0u; // off by default, as in the reference's loop (:199)
+	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : 1u;
 	P.walk_batch = rmd::kWalkBatchDefault;
 	if (ctx && ctx->tunable[RMD_TUNE_WALK_BATCH] > 0) P.walk_batch = (uint32_t)ctx->tunable[RMD_TUNE_WALK_BATCH]; // any value gives the same image
 #if RMD_DIAG

@@ -368,20 +368,32 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			hit.frag = ro + rd * hit_t; // :246, the same operations as at classification
 			hit.color = ld3(o.color), hit.roughness = o.roughness, hit.metal = o.metalness;
 		}
+		[[maybe_unused]] bool black = false; // the path's throughput has become exactly (0, 0, 0)
 		if constexpr (GRID) {
 			V3 T = mk(1.0, 1.0, 1.0);
 			if (to_shade) T = load_T();
 			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T);
 			if (to_shade || prim) store_T(T);
+			black = Pt.end_black_paths != 0u && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
 		} else {
 			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
+			black = Pt.end_black_paths != 0u && T_reg.x == 0.0 && T_reg.y == 0.0 && T_reg.z == 0.0;
 		}
 		rng_block = rng.block;
 		cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
 		if (to_shade) {
 			depth++;
 			to_shade = false;
-			if (depth > Pt.bounce_limit) cut = true, has_ray = false;
+			// A path whose throughput is exactly zero in every channel — a diffuse bounce off a black surface ((1 - F)(1 - metal) (.) (0, 0, 0),
+			// :279-281), a GGX sample below the surface (geometry_smith's max(n.l, 0), :373) — is ended here: whatever its remaining segments
+			// find is multiplied by that zero on the way back up trace()'s recursion (:281-282, :315-318), so the sample is exactly zero in
+			// the reference as well — unless a later vertex produces a non-finite radiance (0 x NaN = NaN).  A scene of planes and spheres
+			// cannot (its one source, r1 = 0 in a diffuse pdf, is the 2^-53 case of DESIGN.md section 3); on a mesh the Heron normal of a
+			// degenerate hit can (~1e-9 per sample on the benchmark mesh): there the reference's sample is NaN and this one 0, unless the
+			// caller sets RMD_RENDER_TRACE_BLACK_PATHS, which keeps tracing such paths.  Three of the reference scenes' six walls are
+			// black: a quarter of all path segments (a third with the mesh) belong to paths that can no longer contribute.  The explicit
+			// (x, y, sample) probes always trace them — they record the reference's hit sequence.
+			if (depth > Pt.bounce_limit || (!LIST && black)) cut = true, has_ray = false;
 			else has_ray = true, new_ray = true;
 		}
 #if RMD_DIAG

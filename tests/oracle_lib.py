@@ -54,6 +54,7 @@ _SIGS = {
     "orc_mesh_destroy": (None, [_vp]),
     "orc_resolve_tonemap": (None, [_vp, _sz, C.c_double, C.c_double, C.c_double, _vp]),
     "orc_set_mutation": (C.c_int32, [C.c_int32]),
+    "orc_count_black_paths": (None, [C.c_int32]),
     "orc_counters_reset": (None, []),
     "orc_counters_get": (None, [_vp]),
 }

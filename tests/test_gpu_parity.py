@@ -458,6 +458,35 @@ def test_config1_image(gpu_ctx, oracle):
     ds.close()
 
 
+def test_ending_black_paths_changes_no_sample(gpu_ctx, oracle, small_mesh_scene):
+    """By default a path whose throughput has become exactly (0, 0, 0) — a diffuse bounce off a black wall, a GGX sample below the surface — is
+    ended: trace() multiplies whatever the rest of the path finds by that zero, so the sample is zero in the reference too.  The frame
+    must equal, bit for bit, the one RMD_RENDER_TRACE_BLACK_PATHS gives (every segment traced, as the reference does) and the oracle's
+    — wherever the reference's sample is finite: a pixel may only differ where tracing on met a non-finite radiance (0 x NaN)."""
+    from raymond_amd.scene import Material, Object, Plane, Scene, Sphere
+
+    cases = [(scenes.reflective_spheres(), 203, 117, 24, 5), (small_mesh_scene, 160, 96, 12, 8)]
+    for sc, W, H, spp, bounces in cases:
+        tiles = generate_tiles(W, H, (32, 32))
+        ds = render.DeviceScene(gpu_ctx, sc)
+        fb = render.Framebuffer(gpu_ctx, W, H)
+        frames = {}
+        for trace_on in (False, True):
+            st = Settings(scenes.camera(W, H), sample_count=spp, bounce_limit=bounces, seed=41, trace_black_paths=trace_on)
+            fb.zero()
+            render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
+            frames[trace_on] = fb.download()
+        same = (frames[False] == frames[True]).all(axis=2)
+        assert np.isfinite(frames[True][~same]).all(axis=1).sum() == 0, "a finite pixel changed"
+        assert same.mean() > 0.9999 and np.isfinite(frames[False]).all()
+        ref = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=4)
+        ok = rel_close(frames[False], ref, 1e-9).all(axis=2)
+        assert ok.mean() >= 0.995
+        # and it is a large share of the work: the black back and side walls end a third of the paths early
+        assert (frames[False] == 0.0).all(axis=2).mean() < 0.5  # (the frame itself is not black)
+        fb.close(), ds.close()
+
+
 def test_output_stage_is_byte_exact_on_adversarial_frames(gpu_ctx, oracle):
     """`rmd_resolve_tonemap` == the oracle's restatement of `TaskHandle::await`'s division + cli_old/src/main.rs:161-181, byte for byte, on
     frames built to sit ON the truncation boundaries — radiances whose 255 * tm is an integer to within an ulp or a few 1e-13, for every

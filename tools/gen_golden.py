@@ -185,12 +185,18 @@ def work_counters(only=()):
         st = scenes.config_settings(name, spp=spp)
         cam = st.camera_settings
         sc = getattr(scenes, scenes.CONFIGS[name][0])(grid_builder=lambda m: O.grid_build(m)[1]) if name in ("C3", "C4", "C5") else scenes.reflective_spheres()
-        O.counters_reset()
-        O.OracleScene(sc).render_tiles(cam, st, generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size))
-        c = O.counters()
-        c["config"] = "%s %dx%d %d spp %d bounces" % (name, cam.backbuffer_width, cam.backbuffer_height, spp, st.bounce_limit)
-        out[name] = c
-        print(name, c, flush=True)
+        # <name>: the work of the product's default, which ends a path whose bounce weights multiply to exactly zero (its sample is zero in
+        # the reference too); <name>_reference: everything the reference executes (RMD_RENDER_TRACE_BLACK_PATHS)
+        for key, count_black in ((name, 0), (name + "_reference", 1)):
+            O.load().orc_count_black_paths(count_black)
+            O.counters_reset()
+            O.OracleScene(sc).render_tiles(cam, st, generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size))
+            c = O.counters()
+            c["config"] = "%s %dx%d %d spp %d bounces%s" % (name, cam.backbuffer_width, cam.backbuffer_height, spp, st.bounce_limit,
+                                                          ", path segments behind a zero bounce weight included" if count_black else "")
+            out[key] = c
+            print(key, c, flush=True)
+        O.load().orc_count_black_paths(0)
     with open(os.path.join(GOLD, "work_counters.json"), "w") as f:
         json.dump(out, f, indent=1)
 
