@@ -188,8 +188,9 @@ def main():
             else:
                 dist.barrier()
 
-    def setup(name, spp):
+    def setup(name, spp, trace_black_paths=False):
         st = scenes.config_settings(name, spp=spp)
+        st.trace_black_paths = trace_black_paths
         cam = st.camera_settings
         sc = getattr(scenes, scenes.CONFIGS[name][0])()
         tiles = generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size)
@@ -217,8 +218,8 @@ def main():
         abi_comm = C.c_void_p()
         ctx.check(ctx.L.rmd_comm_create(ctx.handle, uid, rank, world, C.byref(abi_comm)))
 
-    def run_workload(name, spp, steps, warmup, reduce):
-        st, cam, sc, tiles, share = setup(name, spp)
+    def run_workload(name, spp, steps, warmup, reduce, trace_black_paths=False):
+        st, cam, sc, tiles, share = setup(name, spp, trace_black_paths)
         W, H = cam.backbuffer_width, cam.backbuffer_height
         ds = render.DeviceScene(ctx, sc)
         fb_t = torch.zeros(W * H * 3, dtype=torch.float64, device=dev)
@@ -300,6 +301,15 @@ def main():
         },
     }
 
+    # for the record, beside `value`: the same frame with every path traced to its end as the reference does (RMD_RENDER_TRACE_BLACK_PATHS) —
+    # the same checksum, the reference's full number of path segments
+    if world == 1 and not args.no_roofline_leg:
+        full = run_workload(name, spp, 1, 1, reduce=False, trace_black_paths=True)
+        out["tracing_black_paths"] = {
+            "value": round(full["samples_per_step"] / full["elapsed"] / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(full["elapsed"] * 1e3, 3),
+            "checksum": full["checksum"],
+            "note": "rmd_settings.flags = RMD_RENDER_TRACE_BLACK_PATHS: paths whose throughput is exactly (0, 0, 0) are traced on; same frame, not what `value` measures",
+        }
     if rank == 0:
         counters = load_counters()
         avg_ms = sum(main_run["kernel_ms"]) / len(main_run["kernel_ms"])
