@@ -153,11 +153,15 @@ typedef struct rmd_tile_rect {
  * Every consumer takes exactly one block, in the order the reference makes its calls within a sample:
  *     block 0               pixel jitter: x <- u_first, y <- u_second (:326-327)
  *     then, thin lens only  one block per round of the rejection loop: r1 <- u_first, r2 <- u_second (:340-341)
- *     then                  one block per shaded depth: r1 <- u_first, r2 <- u_second (:397-398 or :287-288) and
- *                           r <- u_22 (:260).  r only decides diffuse against specular: it is compared with prob_d, which
- *                           is 0.5 for Diffuse and 0.0 for Metal (:263-264), and for those two values a 22-bit uniform
- *                           gives exactly the probabilities a 53-bit one does.
- * (One Philox evaluation per path segment, and no RNG state beyond a block counter.)
+ *     then                  one block per shaded depth: r1 <- u_first, r2 <- u_second (:397-398 or :287-288), and
+ *                           r (:260) <- u_22 of the sample's PREVIOUS block (the jitter block or the last lens round for the first
+ *                           depth, the preceding depth's block afterwards).  r only decides diffuse against specular: it is compared
+ *                           with prob_d, which is 0.5 for Diffuse and 0.0 for Metal (:263-264), and for those two values a 22-bit
+ *                           uniform gives exactly the probabilities a 53-bit one does.  Taking it from the previous block makes a
+ *                           hit's lobe known when the hit is: a diffuse bounce off a black surface ends its path (see
+ *                           RMD_RENDER_TRACE_BLACK_PATHS) without the depth's block ever being drawn.  (ABI 2; ABI 1 took r from
+ *                           the depth's own block: same distribution, different samples.)
+ * (One Philox evaluation per path segment, and no RNG state beyond a block counter and those 22 bits.)
  */
 
 typedef struct rmd_context rmd_context;

@@ -164,6 +164,7 @@ struct Rng {
 	uint32_t key[2];
 	uint32_t pixel, sample;
 	uint32_t block = 0;
+	double lobe = 0.0; /* the 22-bit uniform of the path's last block: `r` (:260) of the NEXT shaded depth */
 	Rng(uint64_t seed, uint32_t pixel_, uint32_t sample_) : pixel(pixel_), sample(sample_) {
 		key[0] = (uint32_t)seed;
 		key[1] = (uint32_t)(seed >> 32);
@@ -179,15 +180,17 @@ struct Rng {
 		u22 = (double)(((w[0] & 0x7FFu) << 11) | (w[2] & 0x7FFu)) * (1.0 / 4194304.0);
 	}
 	void next2(double &u0, double &u1) { /* two rand::random::<f64>() calls */
-		double unused;
 		ORC_COUNT(K_DRAWS, 2);
-		at(key, pixel, sample, block++, u0, u1, unused);
+		at(key, pixel, sample, block++, u0, u1, lobe);
 	}
 	/* the three calls of one shaded depth, in the reference's order r, r1, r2.  r is only ever compared with prob_d = 0.5
-	 * (Diffuse) or 0.0 (Metal) (:263-264): the 22-bit uniform gives those comparisons the probabilities a 53-bit one does */
+	 * (Diffuse) or 0.0 (Metal) (:263-264): a 22-bit uniform gives those comparisons the probabilities a 53-bit one does.  It is the
+	 * 22-bit uniform of the path's PREVIOUS block (the jitter block for the first depth), so that the lobe of a hit is known when the hit
+	 * is — before the depth's own block is drawn (include/raymond_hip.h "RNG") */
 	void next3(double &r, double &r1, double &r2) {
 		ORC_COUNT(K_DRAWS, 3);
-		at(key, pixel, sample, block++, r1, r2, r);
+		r = lobe;
+		at(key, pixel, sample, block++, r1, r2, lobe);
 	}
 };
 

@@ -220,6 +220,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: |roughness| > 512 is not supported");
 		d.roughness = o.material.roughness;
 		d.metalness = o.material.kind == RMD_MAT_METAL ? 1.0 : 0.0; // src/trace.rs:248-249
+		if (o.material.kind == RMD_MAT_DIFFUSE && o.material.color[0] == 0.0 && o.material.color[1] == 0.0 && o.material.color[2] == 0.0) d.flags |= rmd::kObjBlackDiffuse;
 	}
 	// pair_opposite_planes: plane j is tested together with the first earlier, still unpaired plane i whose normal is its exact negation
 	// (device_core.hpp: plane_pair_intersect — the facing conditions of such planes exclude each other, one division serves both)

@@ -147,7 +147,9 @@ RMD_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 // each round of the thin lens' rejection loop one block, each shaded depth one block.  The state is the next block's index.
 struct Rng {
 	uint32_t pixel, sample, block;
-	RMD_DEV void init(uint32_t pixel_, uint32_t sample_) { pixel = pixel_, sample = sample_, block = 0u; }
+	uint32_t lobe_bits; // the 22 spare bits of the path's last block: `r` (:260) of the NEXT shaded depth, r = lobe_bits * 2^-22
+	RMD_DEV void init(uint32_t pixel_, uint32_t sample_) { pixel = pixel_, sample = sample_, block = 0u, lobe_bits = 0u; }
+	static RMD_DEV uint32_t spare22(uint32_t w0, uint32_t w2) { return ((w0 & 0x7FFu) << 11) | (w2 & 0x7FFu); }
 	static RMD_DEV double to_unit(uint32_t lo, uint32_t hi) { // 53-bit uniform in [0, 1), as rand 0.6's f64
 		uint64_t bits = (((uint64_t)hi << 32) | lo) >> 11;
 		return (double)bits * (1.0 / 9007199254740992.0);
@@ -160,15 +162,18 @@ struct Rng {
 		philox4x32_10(pixel, sample, block, 0u, k0, k1, w0, w1, w2, w3);
 		block++;
 		u0 = to_unit(w0, w1), u1 = to_unit(w2, w3);
+		lobe_bits = spare22(w0, w2);
 	}
 	// the three draws of one shaded depth: r (:260) decides diffuse against specular — it is only ever compared with 0.5
 	// (Diffuse) or 0.0 (Metal) (:263-264), for which a 22-bit uniform gives the same probabilities as a 53-bit one — and r1, r2
 	// (:397-398 or :287-288) are the block's two 53-bit uniforms
 	RMD_DEV void next3(uint32_t k0, uint32_t k1, double &r, double &r1, double &r2) {
 		uint32_t w0, w1, w2, w3;
+		r = (double)lobe_bits * (1.0 / 4194304.0); // of the path's previous block
 		philox4x32_10(pixel, sample, block, 0u, k0, k1, w0, w1, w2, w3);
 		block++;
-		r = to_unit22(w0, w2), r1 = to_unit(w0, w1), r2 = to_unit(w2, w3);
+		r1 = to_unit(w0, w1), r2 = to_unit(w2, w3);
+		lobe_bits = spare22(w0, w2);
 	}
 };
 
@@ -447,13 +452,14 @@ struct NextRayShadeIn {
 RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const NextRayShadeIn &in, V3 cam_pos, uint32_t prim_x, uint32_t prim_y, Rng &rng,
                       V3 &ro, V3 &rd, V3 &T) {
 	const bool gen = do_shade || do_prim;
-	double u_first = 0.0, u_second = 0.0, r = 0.0;
+	double u_first = 0.0, u_second = 0.0;
+	const double r = (double)rng.lobe_bits * (1.0 / 4194304.0); // shade only (:260): the 22-bit uniform of the path's previous block
 	if (gen) {
 		uint32_t w0, w1, w2, w3;
 		philox4x32_10(rng.pixel, rng.sample, rng.block, 0u, P.key0, P.key1, w0, w1, w2, w3);
 		rng.block++;
 		u_first = Rng::to_unit(w0, w1), u_second = Rng::to_unit(w2, w3);
-		r = Rng::to_unit22(w0, w2); // shade only (:260)
+		rng.lobe_bits = Rng::spare22(w0, w2); // for the next shaded depth
 	}
 	// ---- SHADE, first half: the direction before its normalisation
 	V3 pre = mk(0.0, 0.0, 1.0), view = pre, f0 = pre;

@@ -20,8 +20,11 @@ struct alignas(16) DevObject {
 	double roughness;
 	double color[3]; // Diffuse/Metal colour, Emission radiance
 	double metalness; // 0.0 Diffuse, 1.0 Metal (src/trace.rs:248-249)
-	double _pad1[2];
+	uint32_t flags;   // kObj*
+	uint32_t _pad2;
+	double _pad1;
 };
+constexpr uint32_t kObjBlackDiffuse = 1u; // Diffuse with colour (0, 0, 0): its diffuse bounce has weight exactly zero (src/trace.rs:279-281)
 static_assert(sizeof(DevObject) == 128, "DevObject layout");
 constexpr uint32_t kPairTestedAtPartner = 0x80000000u;
 

@@ -165,7 +165,8 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 	}
 
 	const V3 cam_pos = ld3(P.cam_pos);
-	uint32_t rng_block = 0; // index of the sample's next Philox block — all the RNG state a path carries (the key is its pixel and sample)
+	uint32_t rng_block = 0; // index of the sample's next Philox block — with lobe_bits all the RNG state a path carries (the key is its pixel and sample)
+	uint32_t lobe_bits = 0; // the 22 spare bits of the path's last block: they decide diffuse against specular at its next shaded depth
 	V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
 	uint32_t depth = 1; // depth argument of the trace() call being evaluated
 	// throughput: product of the bounce weights of the path so far.  It is read and written once per bounce and read when the path ends;
@@ -284,7 +285,13 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 					// returns NaN and this kernel 0).
 					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
 					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
-					if (depth == Pt.bounce_limit && finite_inputs) {
+					// ... and so is a diffuse bounce off a black surface (o.flags: Diffuse, colour (0, 0, 0)): its weight (1 - F)(1 - metal) (.) colour
+					// (:279-281) is exactly zero for finite inputs, so the path ends here with the sample the reference computes — zero — see the
+					// throughput rule below.  Whether the bounce is the diffuse one (`r < prob_d`, :263-264, prob_d = 0.5 for Diffuse) is known
+					// now: r is the 22-bit uniform of the path's PREVIOUS block.  The lane takes its next sample on this very trip instead of
+					// shading, finding its throughput zero and sitting out the intersection phase.
+					const bool black_bounce = !LIST && Pt.end_black_paths != 0u && (o.flags & kObjBlackDiffuse) != 0u && lobe_bits < (1u << 21);
+					if ((depth == Pt.bounce_limit || black_bounce) && finite_inputs) {
 						terminal = true; // L = 0
 					} else {
 						if constexpr (GRID) parked[0] = normal.x, parked[64] = normal.y, parked[128] = normal.z, parked[192] = t, parked_obj[0] = oi;
@@ -349,7 +356,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			s = Pt.sample_begin + pool_first + (item >> 6);
 		}
 		Rng rng;
-		rng.pixel = y * Pt.W + x, rng.sample = s, rng.block = rng_block;
+		rng.pixel = y * Pt.W + x, rng.sample = s, rng.block = rng_block, rng.lobe_bits = lobe_bits;
 		lens_failed = false;
 		if (Pt.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
 			if (prim) {
@@ -379,7 +386,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
 			black = Pt.end_black_paths != 0u && T_reg.x == 0.0 && T_reg.y == 0.0 && T_reg.z == 0.0;
 		}
-		rng_block = rng.block;
+		rng_block = rng.block, lobe_bits = rng.lobe_bits;
 		cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
 		if (to_shade) {
 			depth++;
