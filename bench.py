@@ -57,13 +57,17 @@ def load_counters():
         return json.load(f)
 
 
-def algorithmic_bytes_per_sample(name, spp, counters):
-    """8*C + 76*T + 72*H + 24/spp bytes per sample (C cells, T triangle tests, H shaded mesh hits)."""
+def algorithmic_bytes_per_sample(name, spp, counters, all_cells=False):
+    """8*C + 76*T + 72*H + 24/spp bytes per sample (T triangle tests, H shaded mesh hits) with C = the visited cells that hold a
+    triangle: only those gather their 8-byte entry from memory — an empty cell is answered by one bit of the occupancy mask in LDS, which
+    is part of the data layout (round 2's advisor: "count 8 B only for occupied cells").  all_cells=True prices every
+    visited cell at 8 bytes, §8d to the letter (what rounds 1 and 2 reported)."""
     c = counters.get(name)
     if c is None:
         return None
     n = float(c["samples"])
-    return 8.0 * c["cells"] / n + 76.0 * c["tri_tests"] / n + 72.0 * c["mesh_hits"] / n + 24.0 / spp
+    cells = c["cells"] if all_cells or "occupied_cells" not in c else c["occupied_cells"]
+    return 8.0 * cells / n + 76.0 * c["tri_tests"] / n + 72.0 * c["mesh_hits"] / n + 24.0 / spp
 
 
 def usable_cpus():
@@ -356,11 +360,12 @@ def main():
             "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch" % rspp,
             "kernel": "rmd::render_kernel<1, true, true> + rmd::sum_kernel", "avg_ms": round(avg_ms, 3), "launch_ms": [round(v, 3) for v in rr["kernel_ms"]],
             "bytes_per_sample": round(bps, 2), "bytes_per_launch": bps * rr["samples_per_step"],
+            "frac_with_every_visited_cell_at_8_bytes": algorithmic_bytes_per_sample("C3", rspp, counters, all_cells=True) * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "definition": "achieved / frac = ALGORITHMIC bytes per launch / launch time — most of these bytes are answered by LDS (occupancy mask), L2 and the "
                           "Infinity Cache; measured_gbs / measured_frac = L2<->fabric bytes by PMC, an upper bound on HBM bytes",
             "bound_by_counters": "valu issue (see `valu`: ~0.85 of the issue slots busy at ~51 % lanes)",
             "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
-            "how": "achieved = algorithmic bytes per launch (8 B x cells visited + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
+            "how": "achieved = algorithmic bytes per launch (8 B x visited cells that hold a triangle + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
                    "oracle counters in tests/golden/work_counters.json — of the work the default does: path segments behind a bounce weight of exactly "
                    "zero are not counted, C3_reference holds the reference's full count — + 24 B/pixel) / mean launch duration from HIP events on the launch stream; "
                    "profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true> (persistent workgroups) + sum_kernel over the same launches",

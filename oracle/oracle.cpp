@@ -96,9 +96,9 @@ inline bool mut(int k) { return g_mutation == k; }
 
 /* ------------------------------------------------------------------ work counters */
 struct Counters {
-	uint64_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	uint64_t c[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
-enum { K_SAMPLES, K_SEGMENTS, K_CELLS, K_TRI_TESTS, K_MESH_HITS, K_BOUNCES, K_DRAWS, K_WALKS };
+enum { K_SAMPLES, K_SEGMENTS, K_CELLS, K_TRI_TESTS, K_MESH_HITS, K_BOUNCES, K_DRAWS, K_WALKS, K_OCCUPIED_CELLS /* visited cells that hold a triangle */, K_COUNT = 12 };
 std::mutex g_counter_mutex;
 Counters g_counters;
 thread_local Counters tl_counters;
@@ -130,7 +130,7 @@ inline void hist_add(int kind, uint64_t v) { g_walk_hist[kind][v > 64 ? 64 : v]+
 #endif
 void flush_counters() {
 	std::lock_guard<std::mutex> lock(g_counter_mutex);
-	for (int i = 0; i < 8; i++) {
+	for (int i = 0; i < K_COUNT; i++) {
 		g_counters.c[i] += tl_counters.c[i];
 		tl_counters.c[i] = 0;
 	}
@@ -467,6 +467,7 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 		uint64_t cell = g.cells[idx];
 		uint64_t count = g.mapping_table[cell];
 		w_cells++, w_tests += count, w_nonempty += count > 0, w_maxc = std::max(w_maxc, count);
+		if (count > 0) ORC_COUNT(K_OCCUPIED_CELLS, 1);
 		double closest = 5712515.0;
 		Hit closest_hit = hit_none();
 		for (uint64_t i = 1; i <= count; i++) {
@@ -1222,10 +1223,10 @@ void orc_counters_reset(void) {
 	std::lock_guard<std::mutex> lock(g_counter_mutex);
 	g_counters = Counters();
 }
-void orc_counters_get(uint64_t out[8]) {
+void orc_counters_get(uint64_t out[12]) {
 	flush_counters();
 	std::lock_guard<std::mutex> lock(g_counter_mutex);
-	for (int i = 0; i < 8; i++) out[i] = g_counters.c[i];
+	for (int i = 0; i < K_COUNT; i++) out[i] = g_counters.c[i];
 }
 
 } // extern "C"

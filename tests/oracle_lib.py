@@ -229,9 +229,9 @@ def block_uniforms(seed, pixel, sample, block):
 
 
 def counters():
-    out = np.zeros(8, dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
     load().orc_counters_get(ptr(out))
-    names = ["samples", "segments", "cells", "tri_tests", "mesh_hits", "bounces", "draws", "walks"]
+    names = ["samples", "segments", "cells", "tri_tests", "mesh_hits", "bounces", "draws", "walks", "occupied_cells"]
     return dict(zip(names, (int(v) for v in out)))
 
 
