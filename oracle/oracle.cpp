@@ -98,7 +98,8 @@ inline bool mut(int k) { return g_mutation == k; }
 struct Counters {
 	uint64_t c[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
-enum { K_SAMPLES, K_SEGMENTS, K_CELLS, K_TRI_TESTS, K_MESH_HITS, K_BOUNCES, K_DRAWS, K_WALKS, K_OCCUPIED_CELLS /* visited cells that hold a triangle */, K_COUNT = 12 };
+enum { K_SAMPLES, K_SEGMENTS, K_CELLS, K_TRI_TESTS, K_MESH_HITS, K_BOUNCES, K_DRAWS, K_WALKS, K_OCCUPIED_CELLS /* visited cells that hold a triangle */,
+       K_ZERO_DIFFUSE /* bounces whose weight is exactly zero: diffuse lobe */, K_ZERO_SPECULAR /* ... GGX lobe */, K_COUNT = 12 };
 std::mutex g_counter_mutex;
 Counters g_counters;
 thread_local Counters tl_counters;
@@ -722,6 +723,7 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 			V3 fr = fresnel_schlick(rmax(dot(hw, view_dir), 0.0), f0);
 			V3 a = mul_ew((v3(1.0, 1.0, 1.0) - fr) * (1.0 - material_metalness), material_color);
 			black = (a.x == 0.0 && a.y == 0.0 && a.z == 0.0) || rmax(dot(normal, sample_world), 0.0) == 0.0;
+			if (black) ORC_COUNT(K_ZERO_DIFFUSE, 1);
 		}
 #endif
 		BlackScope scope(black);
@@ -746,6 +748,7 @@ V3 trace(const Ray &ray, TraceContext &ctx, Rng &rng, uint32_t depth) {
 			double n = ((((material_roughness * material_roughness) * rmax(dot(normal, view_dir), 0.0)) * rmax(dot(normal, sample_world), 0.0)) * dot(normal, sample_world)) *
 			           (4.0 * dot(hw, view_dir));
 			black = n == 0.0 || (fr.x == 0.0 && fr.y == 0.0 && fr.z == 0.0);
+			if (black) ORC_COUNT(K_ZERO_SPECULAR, 1);
 		}
 #endif
 		BlackScope scope(black);

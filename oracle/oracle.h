@@ -117,7 +117,7 @@ void orc_count_black_paths(int32_t on);
 void orc_counters_reset(void);
 /* per-walk histograms, buckets 0..63 and 64+ : cells visited, non-empty cells visited, triangle tests, max triangles per cell; [260] = walks that hit */
 void orc_walk_hist(uint64_t out[4 * 65 + 1]);
-void orc_counters_get(uint64_t out[12]); /* samples, segments, cells, tri_tests, mesh_hits, bounces, draws, walks, occupied_cells, 3 x reserved */
+void orc_counters_get(uint64_t out[12]); /* samples, segments, cells, tri_tests, mesh_hits, bounces, draws, walks, occupied_cells, zero_weight_diffuse, zero_weight_specular, reserved */
 
 #ifdef __cplusplus
 }
