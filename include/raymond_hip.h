@@ -239,7 +239,9 @@ rmd_status rmd_render_tiles_host(rmd_context *ctx, const rmd_scene *scene, const
 rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms);
 
 /* ---- output stage (TaskHandle::await src/trace.rs:93-99, cli_old/src/main.rs:155-181) ---- */
-/* out_rgb8[i] = trunc(255 * (1 - exp(-(accum[i]/sample_count) * exposure))^(1/gamma)); device in, host out. */
+/* out_rgb8[i] = trunc(255 * (1 - exp(-(accum[i]/sample_count) * exposure))^(1/gamma)); device in, host out.  A pixel with a channel that is
+ * NaN or outside (-1, 256) stays (0, 0, 0), as cast::<u8>() returning None leaves it (:176-181).  Byte for byte what the host's libm gives:
+ * the device evaluates every pixel and the few whose value lies within 1e-7 of a truncation boundary are recomputed on the host. */
 rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32_t width, uint32_t height,
                                uint32_t sample_count, double exposure, double gamma, uint8_t *out_rgb8_host);
 
