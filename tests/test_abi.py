@@ -116,3 +116,30 @@ def test_product_package_never_touches_the_oracle():
                     assert needle not in text, "%s mentions %s" % (os.path.join(base, f), needle)
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert bench.count("import oracle_lib") == 1 and bench.index("import oracle_lib") > bench.index("not args.no_cpu_baseline")
+
+
+def test_header_constants_match_the_python_mirror():
+    """Flags, tunable keys and the ABI version of include/raymond_hip.h as the C compiler sees them == raymond_amd/abi.py; and Settings
+    builds rmd_settings.flags from them (the thin lens and the trace-everything switch are both opt-in: flags 0 is the default)."""
+    from raymond_amd import scenes
+    from raymond_amd.scene import Settings
+
+    src = r"""
+#include <stdio.h>
+#include "raymond_hip.h"
+int main(void) {
+  printf("%u %u %u %u %u %u %u %u %u\n", RMD_ABI_VERSION, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS, (unsigned)RMD_TUNE_SAMPLE_SPLIT, (unsigned)RMD_TUNE_WALK_BATCH,
+         (unsigned)RMD_TUNE_MASK_BUDGET, (unsigned)RMD_TUNE_LAUNCH_FORM, (unsigned)RMD_TUNE_SCRATCH_CAP_MB, (unsigned)RMD_TUNE_COUNT);
+  return 0; }
+"""
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "consts.c"), os.path.join(d, "consts")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [abi.RMD_ABI_VERSION, abi.RMD_RENDER_DOF, abi.RMD_RENDER_TRACE_BLACK_PATHS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_WALK_BATCH,
+                   abi.RMD_TUNE_MASK_BUDGET, abi.RMD_TUNE_LAUNCH_FORM, abi.RMD_TUNE_SCRATCH_CAP_MB, 5]
+    cam = scenes.camera(64, 48, aperture_radius=0.5)
+    assert Settings(cam, 4).pod().flags == 0
+    assert Settings(cam, 4, use_dof=True).pod().flags == abi.RMD_RENDER_DOF
+    assert Settings(cam, 4, use_dof=True, trace_black_paths=True).pod().flags == (abi.RMD_RENDER_DOF | abi.RMD_RENDER_TRACE_BLACK_PATHS)
