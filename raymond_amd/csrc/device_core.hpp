@@ -583,11 +583,17 @@ RMD_DEV void primary_ray(const RenderParams &P, uint32_t xi, uint32_t yi, double
 	rd = normalize(mk(px, py, 1.0));
 }
 // :335-360.  Returns false where the reference's unwrap() on the focal-plane hit would panic.
+// The lens part of it (:337-359) for a pinhole ray (po, pd) that generate_primary_ray has made already (:336): the render loop takes that ray —
+// jitter block included — from next_ray()'s merged stream and only the rejection loop, the focal plane and the new direction run here.
+RMD_DEV bool thin_lens_from_pinhole(const RenderParams &P, V3 po, V3 pd, Rng &rng, V3 &ro, V3 &rd);
 RMD_DEV bool primary_ray_dof(const RenderParams &P, uint32_t xi, uint32_t yi, Rng &rng, V3 &ro, V3 &rd) {
 	double u0, u1;
 	rng.next2(P.key0, P.key1, u0, u1);
 	V3 po, pd;
 	primary_ray(P, xi, yi, u0, u1, po, pd);
+	return thin_lens_from_pinhole(P, po, pd, rng, ro, rd);
+}
+RMD_DEV bool thin_lens_from_pinhole(const RenderParams &P, V3 po, V3 pd, Rng &rng, V3 &ro, V3 &rd) {
 	V3 pos = ld3(P.cam_pos);
 	V3 start = pos;
 	// unbounded rejection loop in the reference; 4096 rounds at acceptance pi/4 is never reached,

@@ -358,13 +358,6 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		Rng rng;
 		rng.pixel = y * Pt.W + x, rng.sample = s, rng.block = rng_block, rng.lobe_bits = lobe_bits;
 		lens_failed = false;
-		if (Pt.use_dof) { // thin lens (:335-360): a variable number of blocks; not merged with the shading stream
-			if (prim) {
-				store_T(mk(1.0, 1.0, 1.0));
-				lens_failed = !primary_ray_dof(Pt, x, y, rng, ro, rd); // the reference panics there; the sample contributes zero
-			}
-			prim = false;
-		}
 		// the shading inputs of the hit a lane carries — evaluated for every lane, used by next_ray for the lanes that shade (a lane
 		// without a hit reads object 0 and whatever its slots hold: cheaper than nine register moves of stand-in values per trip)
 		NextRayShadeIn hit;
@@ -385,6 +378,10 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		} else {
 			next_ray(Pt, to_shade, prim, hit, cam_pos, x, y, rng, ro, rd, T_reg);
 			black = Pt.end_black_paths != 0u && T_reg.x == 0.0 && T_reg.y == 0.0 && T_reg.z == 0.0;
+		}
+		if (Pt.use_dof) { // thin lens (:335-360): the pinhole ray of :336 has just come out of the merged stream (jitter block included); the rejection
+			// loop's blocks, the focal plane and the new direction follow for the lanes that start a sample
+			if (prim) lens_failed = !thin_lens_from_pinhole(Pt, ro, rd, rng, ro, rd); // the reference panics there; the sample contributes zero
 		}
 		rng_block = rng.block, lobe_bits = rng.lobe_bits;
 		cut = false; // shaded at the bounce limit (non-finite inputs, see below): the recursive call returns 0 unintersected (:235-237)
