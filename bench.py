@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_NS = 1.667  # one wave64 FP64 / INT32 vector instruction per SIMD every 4 cycles at the 2.4 GHz peak clock
 
 
 def parse():
@@ -93,18 +94,41 @@ def usable_cpus():
     return n, quota
 
 
-def load_traffic(name, spp):
-    """Measured L2<->fabric bytes of one launch of workload `name` at `spp` samples per pixel, from the committed rocprofv3
-    --pmc passes (profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes, gfx950 corrections applied), or
-    None when no pass was collected at that spp."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def source_hash():
+    """sha256 (16 hex digits) of the product's device and host sources: the committed PMC figures (profiles/pmc_latest.json,
+    profiles/hbm_traffic.json; tools/pmc_summary.py stores the hash they were collected at) describe the kernels of THAT source."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "raymond_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "raymond_amd", "csrc", "*.cpp")))
+    for f in files + [os.path.join(ROOT, "include", "raymond_hip.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_entry(fname, name, spp):
+    """Entry `name` of a committed PMC summary, with "stale": true when the sources it was measured at are not the ones built now."""
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
         return None
     with open(path) as f:
         entry = json.load(f).get(name)
     if not entry or entry.get("spp") != spp:
         return None
-    return entry["bytes_per_launch"]
+    entry = dict(entry)
+    entry["stale"] = entry.get("source_hash") != source_hash()
+    return entry
+
+
+def load_traffic(name, spp):
+    """Measured L2<->fabric bytes of one launch of workload `name` at `spp` samples per pixel, from the committed rocprofv3
+    --pmc passes (profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes, gfx950 corrections applied), or
+    None when no pass was collected at that spp."""
+    entry = pmc_entry("hbm_traffic.json", name, spp)
+    return entry["bytes_per_launch"] if entry else None
 
 
 def valu_block(name, avg_ms):
@@ -112,23 +136,29 @@ def valu_block(name, avg_ms):
     vector instruction: 1,024 SIMDs x duration / wave instructions.  A wave64 FP64/INT32 vector instruction occupies its SIMD for
     4 cycles (1.67 ns at the 2.4 GHz peak clock; ~1.9 ns at the ~2.1 GHz the part sustains under this load), so a value near
     that means the vector ALUs issue back to back — the launch is VALU-issue bound."""
-    v = load_valu(name)
+    v = pmc_entry("pmc_latest.json", name, 500)
     if not v:
         return None
-    v = dict(v)
     v["simd_ns_per_valu_instr"] = round(avg_ms * 1e6 * 1024.0 / v["wave_instr_valu_per_launch"], 3)
-    v["valu_issue_floor_ns"] = {"at_2.4GHz": 1.667, "note": "4 cycles per wave64 instruction"}
+    v["valu_issue_floor_ns"] = {"at_2.4GHz": VALU_ISSUE_NS, "note": "4 cycles per wave64 instruction"}
+    # the fraction of the vector ALUs' issue slots this launch fills, and the fraction that does useful work (active lanes)
+    v["valu_issue_frac"] = round(VALU_ISSUE_NS / v["simd_ns_per_valu_instr"], 4)
+    v["useful_frac"] = round(v["valu_issue_frac"] * v["lane_utilisation"], 4)
     return v
 
 
-def load_valu(name):
-    """What bounds a VALU-bound launch, from the committed SQ counter pass (profiles/pmc_latest.json, written by
-    tools/pmc_summary.py --json): issue-slot occupancy of the vector ALU, lane utilisation, wave instructions per sample."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f).get(name)
+def bound_by_counters(rl):
+    """Which roof the counters put the launch under: VALU issue when the vector ALUs' issue slots are fuller than the memory pipe
+    (measured L2<->fabric bytes / HBM peak); the text is derived from the numbers of this line."""
+    v = rl.get("valu")
+    if not v:
+        return None, None
+    mem = rl.get("measured_frac")
+    bound = "valu" if mem is None or v["valu_issue_frac"] >= mem else "hbm"
+    text = "%s: %.2f of the VALU issue slots busy at %.1f %% lanes (useful %.2f), measured L2<->fabric traffic %s of the HBM peak%s" % (
+        "VALU issue" if bound == "valu" else "HBM", v["valu_issue_frac"], 100.0 * v["lane_utilisation"], v["useful_frac"],
+        "n/a" if mem is None else "%.3f" % mem, " (PMC figures are STALE: collected at other sources)" if v.get("stale") else "")
+    return bound, text
 
 
 def launch_ranks(n):
@@ -156,6 +186,12 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
+    # every rank, whoever launched it (this script's own parent or the driver's torch.distributed.run): dmabuf IPC for RCCL, set before torch
+    # is imported and before the first HIP call of the process (the HSA runtime reads its environment once)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("RMD_BENCH_ECHO_ENV"):  # tests/test_distributed_gloo.py: what a rank's environment holds, without touching a GPU
+        print(json.dumps({"rank": os.environ.get("RANK", "0"), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]}), flush=True)
+        return
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,9 +228,11 @@ def main():
             else:
                 dist.barrier()
 
-    def setup(name, spp, trace_black_paths=False):
+    def setup(name, spp, mode="default"):
+        # mode: "default" = rmd_settings.flags 0 (+ RMD_RENDER_DOF for C5): the reference-identical mode; "trace" = RMD_RENDER_TRACE_BLACK_PATHS;
+        # "end" = RMD_RENDER_END_BLACK_PATHS (include/raymond_hip.h)
         st = scenes.config_settings(name, spp=spp)
-        st.trace_black_paths = trace_black_paths
+        st.trace_black_paths, st.end_black_paths = mode == "trace", mode == "end"
         cam = st.camera_settings
         sc = getattr(scenes, scenes.CONFIGS[name][0])()
         tiles = generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size)
@@ -222,8 +260,8 @@ def main():
         abi_comm = C.c_void_p()
         ctx.check(ctx.L.rmd_comm_create(ctx.handle, uid, rank, world, C.byref(abi_comm)))
 
-    def run_workload(name, spp, steps, warmup, reduce, trace_black_paths=False):
-        st, cam, sc, tiles, share = setup(name, spp, trace_black_paths)
+    def run_workload(name, spp, steps, warmup, reduce, mode="default"):
+        st, cam, sc, tiles, share = setup(name, spp, mode)
         W, H = cam.backbuffer_width, cam.backbuffer_height
         ds = render.DeviceScene(ctx, sc)
         fb_t = torch.zeros(W * H * 3, dtype=torch.float64, device=dev)
@@ -301,18 +339,20 @@ def main():
                 ", RCCL reduce(sum) of the f64 framebuffer to rank 0" + (" through rmd_reduce_framebuffer" if args.assemble == "abi" else "")) if world > 1 else ""),
             "rng": "philox4x32-10, key = seed, counter = (pixel, sample, block, 0); one block per consumer (jitter, lens round, shaded depth)",
             "seed": scenes.SEED,
-            "paths": "a path whose throughput has become exactly (0, 0, 0) is ended (rmd_settings.flags 0): every sample has the reference's value",
+            "paths": "rmd_settings.flags 0, the reference-identical mode: a path whose throughput has become exactly (0, 0, 0) is ended where that provably "
+                     "changes no sample (scenes without grids, as this one); in scenes with a mesh it is traced on unless RMD_RENDER_END_BLACK_PATHS",
         },
     }
 
     # for the record, beside `value`: the same frame with every path traced to its end as the reference does (RMD_RENDER_TRACE_BLACK_PATHS) —
     # the same checksum, the reference's full number of path segments
     if world == 1 and not args.no_roofline_leg:
-        full = run_workload(name, spp, 1, 1, reduce=False, trace_black_paths=True)
+        full = run_workload(name, spp, 1, 1, reduce=False, mode="trace")
         out["tracing_black_paths"] = {
             "value": round(full["samples_per_step"] / full["elapsed"] / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(full["elapsed"] * 1e3, 3),
             "checksum": full["checksum"],
-            "note": "rmd_settings.flags = RMD_RENDER_TRACE_BLACK_PATHS: paths whose throughput is exactly (0, 0, 0) are traced on; same frame, not what `value` measures",
+            "note": "rmd_settings.flags = RMD_RENDER_TRACE_BLACK_PATHS: paths whose throughput is exactly (0, 0, 0) are traced on (1.8x the path segments); the same frame "
+                    "bit for bit (same checksum) — the segment count the CPU baseline executes; not what `value` measures",
         }
     if rank == 0:
         counters = load_counters()
@@ -339,44 +379,79 @@ def main():
         if name == "C2":
             # the real bound of this workload: FP64 vector-ALU issue (the 8-object scene lives in LDS/SGPRs, HBM sees the framebuffer only)
             rl["note"] = "VALU-issue bound, not HBM bound: see `valu`"
-            rl["bound_by_counters"] = "valu"
             v = valu_block("C2", avg_ms) if spp == 500 else None
             if v:
                 rl["valu"] = v
+                rl["bound"], rl["bound_by_counters"] = bound_by_counters(rl)
         out["roofline_%s" % name.lower()] = rl
 
-    # roofline leg: the traversal on the ~100k-triangle mesh (config C3, reduced spp; throughput is spp-independent)
+    # roofline leg: the traversal on the ~100k-triangle mesh — config C3 at its 500 spp, ONE launch per step — in the reference-identical
+    # mode (flags 0: every path traced to its end on a mesh scene) and, beside it, with RMD_RENDER_END_BLACK_PATHS
     if not args.no_roofline_leg and world == 1:
         rspp = args.roofline_spp if args.roofline_spp is not None else scenes.CONFIGS["C3"][3]
-        rr = run_workload("C3", rspp, args.roofline_steps, 1, reduce=False)
         counters = load_counters()
-        bps = algorithmic_bytes_per_sample("C3", rspp, counters)
-        avg_ms = sum(rr["kernel_ms"]) / len(rr["kernel_ms"])
-        ach = bps * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9
-        traffic = load_traffic("C3", rspp)
-        out["roofline"] = {
-            "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch" % rspp,
-            "kernel": "rmd::render_kernel<1, true, true> + rmd::sum_kernel", "avg_ms": round(avg_ms, 3), "launch_ms": [round(v, 3) for v in rr["kernel_ms"]],
-            "bytes_per_sample": round(bps, 2), "bytes_per_launch": bps * rr["samples_per_step"],
-            "frac_with_every_visited_cell_at_8_bytes": algorithmic_bytes_per_sample("C3", rspp, counters, all_cells=True) * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+
+        def mesh_leg(mode, steps, counter_key, pmc_key):
+            rr = run_workload("C3", rspp, steps, 1, reduce=False, mode=mode)
+            bps = algorithmic_bytes_per_sample(counter_key, rspp, counters)
+            avg_ms = sum(rr["kernel_ms"]) / len(rr["kernel_ms"])
+            ach = bps * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9
+            traffic = load_traffic(pmc_key, rspp)
+            leg = {
+                "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_ms": round(avg_ms, 3), "launch_ms": [round(v, 3) for v in rr["kernel_ms"]],
+                "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
+                "bytes_per_sample": round(bps, 2), "bytes_per_launch": bps * rr["samples_per_step"],
+                "frac_with_every_visited_cell_at_8_bytes": algorithmic_bytes_per_sample(counter_key, rspp, counters, all_cells=True) * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "checksum": rr["checksum"],
+            }
+            if traffic is not None:
+                # L2<->fabric bytes per launch by PMC (upper bound on HBM bytes: Infinity-Cache hits are included)
+                leg["measured_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 3)
+                leg["measured_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                leg["traffic_stale"] = pmc_entry("hbm_traffic.json", pmc_key, rspp)["stale"]
+            v = valu_block(pmc_key, avg_ms) if rspp == 500 else None
+            if v:
+                leg["valu"] = v
+                leg["valu_issue_frac"], leg["useful_frac"] = v["valu_issue_frac"], v["useful_frac"]
+                leg["bound"], leg["bound_by_counters"] = bound_by_counters(leg)
+            return leg
+
+        rl = mesh_leg("default", args.roofline_steps, "C3_reference", "C3")
+        rl.update({
+            "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch; rmd_settings.flags 0 = "
+                        "reference-identical: every path traced to its end" % rspp,
+            "kernel": "rmd::render_kernel<1, true, true> + rmd::sum_kernel",
             "definition": "achieved / frac = ALGORITHMIC bytes per launch / launch time — most of these bytes are answered by LDS (occupancy mask), L2 and the "
-                          "Infinity Cache; measured_gbs / measured_frac = L2<->fabric bytes by PMC, an upper bound on HBM bytes",
-            "bound_by_counters": "valu issue (see `valu`: ~0.85 of the issue slots busy at ~51 % lanes)",
-            "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
+                          "Infinity Cache, so the figure saturates and does not rank kernels any more; measured_gbs / measured_frac = L2<->fabric bytes by PMC, "
+                          "an upper bound on HBM bytes; valu_issue_frac = 1.667 ns / (ns per wave-level vector instruction per SIMD): the bound that binds; "
+                          "useful_frac = valu_issue_frac x lane utilisation",
             "how": "achieved = algorithmic bytes per launch (8 B x visited cells that hold a triangle + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
-                   "oracle counters in tests/golden/work_counters.json — of the work the default does: path segments behind a bounce weight of exactly "
-                   "zero are not counted, C3_reference holds the reference's full count — + 24 B/pixel) / mean launch duration from HIP events on the launch stream; "
-                   "profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true> (persistent workgroups) + sum_kernel over the same launches",
-        }
-        if traffic is not None:
-            # L2<->fabric bytes per launch by PMC (upper bound on HBM bytes: Infinity-Cache hits are included)
-            out["roofline"]["measured_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 3)
-            out["roofline"]["measured_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        v = valu_block("C3", avg_ms) if rspp == 500 else None
-        if v:
-            out["roofline"]["valu"] = v
+                   "oracle counters in tests/golden/work_counters.json: C3_reference for flags 0, C3 for ending_black_paths, + 24 B/pixel) / mean launch duration "
+                   "from HIP events on the launch stream; profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true> (persistent workgroups) + "
+                   "sum_kernel over the same launches; valu / traffic: committed rocprofv3 --pmc passes (separate SQ / FETCH_SIZE / WRITE_SIZE passes), "
+                   "\"stale\": true when the sources have changed since",
+        })
+        end = mesh_leg("end", max(1, args.roofline_steps - 1), "C3", "C3_end")
+        end["note"] = ("rmd_settings.flags = RMD_RENDER_END_BLACK_PATHS (opt-in on mesh scenes): zero-throughput paths ended; every sample that is finite in the "
+                       "reference keeps its value bit for bit, a sample the reference makes NaN behind a zero weight comes out (0, 0, 0)")
+        rl["ending_black_paths"] = end
+        out["roofline"] = rl
+        # the other mesh configurations of BASELINE.json on this GPU, short launches (throughput does not depend on the sample count): both modes
+        cfg = {}
+        for cname, cspp in (("C4", 20), ("C5", 50)):
+            for mode in ("default", "end"):
+                r = run_workload(cname, cspp, 1, 1, reduce=False, mode=mode)
+                ms = sum(r["kernel_ms"]) / len(r["kernel_ms"])
+                cfg.setdefault(cname, {"workload": "%s, %dx%d, %d bounces%s; %d-spp launch of the config's %d" % (
+                    scenes.CONFIGS[cname][0], r["W"], r["H"], r["st"].bounce_limit, ", thin lens (RMD_RENDER_DOF)" if r["st"].use_dof else "", cspp, scenes.CONFIGS[cname][3])})
+                cfg[cname]["reference_identical" if mode == "default" else "ending_black_paths"] = {
+                    "kernel_ms": round(ms, 3), "msamples_per_s": round(r["samples_per_step"] / (ms * 1e-3) / 1e6, 2)}
+        cfg["C3"] = {"workload": rl["workload"], "reference_identical": {"kernel_ms": rl["avg_ms"], "msamples_per_s": rl["msamples_per_s"]},
+                     "ending_black_paths": {"kernel_ms": end["avg_ms"], "msamples_per_s": end["msamples_per_s"]}}
+        cfg["C2"] = {"workload": out["config"]["workload"], "reference_identical": {"kernel_ms": out["kernel"]["avg_ms"], "msamples_per_s": round(value, 2)},
+                     "tracing_black_paths": {"kernel_ms": out["tracing_black_paths"]["ms_per_step"], "msamples_per_s": out["tracing_black_paths"]["value"]}}
+        out["configs"] = cfg
     elif rank == 0:
         out["roofline"] = out.get("roofline_%s" % name.lower())
 
@@ -404,6 +479,12 @@ def main():
             % (name, cam.backbuffer_width, cam.backbuffer_height, cpu_spp, n / 1e6, dt, cores, "" if quota is None else " of %.1f CPUs" % quota),
         }
         out["speedup_vs_cpu_baseline"] = round(value / (n / dt / 1e6), 1)
+        if "tracing_black_paths" in out:
+            # like for like: the port traces every path to its end (1.8x the segments of the default on this scene)
+            out["speedup_vs_cpu_baseline_same_segments"] = round(out["tracing_black_paths"]["value"] / (n / dt / 1e6), 1)
+            out["cpu_baseline"]["note"] = ("the port executes the reference's full segment count; `speedup_vs_cpu_baseline` divides the default rate (zero-throughput "
+                                           "paths ended: exact on this scene, and a CPU port could do the same) by it, `speedup_vs_cpu_baseline_same_segments` the "
+                                           "rate with every path traced")
         # the reference's README quotes its ReflectiveSpheres time on a "4 core i5" (0.268 Msamples/s at 592x340): same port on 4 threads
         spp4 = max(1, min(cpu_spp, int(8.0 / max(t1 * cores / 4.0, 1e-3))))
         st4 = scenes.config_settings(name, spp=spp4)

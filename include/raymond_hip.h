@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RMD_ABI_VERSION 2u
+#define RMD_ABI_VERSION 3u
 
 typedef int32_t rmd_status;
 enum {
@@ -124,17 +124,29 @@ typedef struct rmd_camera {
  * RNG definition the reference lacks (it uses the unseedable thread_rng). */
 #define RMD_RENDER_DOF 1u /* rmd_settings.flags: primary rays through generate_primary_ray_with_dof (an extension: the
                              reference defines that function but its render loop never calls it) */
-#define RMD_RENDER_TRACE_BLACK_PATHS 2u /* rmd_settings.flags: keep tracing a path whose throughput has become exactly (0, 0, 0).  By default such a
-                             path is ended — its sample is exactly zero in the reference too, because trace() multiplies whatever the remaining
-                             segments find by that zero — with ONE difference: where a later vertex of such a path produces a non-finite radiance
-                             (the Heron normal of a degenerate mesh hit: ~1e-9 per sample on a 100k-triangle mesh; never in a scene of planes and
-                             spheres) the reference's sample is 0 x NaN = NaN and the default's is 0.  With this flag every sample is the
-                             reference's, NaN included, at the reference's cost (a quarter to a third more path segments in its scenes). */
+/* Paths whose throughput has become exactly (0, 0, 0) — a diffuse bounce off a black surface ((1 - F)(1 - metal) (.) (0,0,0), src/trace.rs:279-281),
+ * a GGX sample below the surface (geometry_smith's max(n.l, 0), :373).  trace() multiplies whatever the rest of such a path finds by that zero
+ * (:281-282, :315-318), so its sample is exactly (0, 0, 0) in the reference too — unless a LATER vertex of the path produces a non-finite
+ * radiance, because 0 x NaN = NaN.  The one source of such a vertex is the interpolated normal of a mesh hit (triangle.rs:47-68: Heron's
+ * radicand rounding below zero for a hit on an edge, or vertex normals that sum to zero); a scene of planes and spheres has none.
+ *
+ *   flags = 0 (default)               REFERENCE-IDENTICAL on every scene.  Such paths are ended early exactly where that cannot change a
+ *                                     sample: in scenes WITHOUT grid objects.  In a scene with a grid they are traced to their end, as
+ *                                     the reference does, so a sample that is NaN in the reference is NaN here.  This is what a drop-in
+ *                                     caller gets (integration/gpu.rs).
+ *   RMD_RENDER_END_BLACK_PATHS        opt-in, scenes with grids: end such paths there too.  Every sample that is finite in the reference
+ *                                     keeps its value bit for bit; a sample the reference makes NaN behind a zero weight comes out (0, 0, 0)
+ *                                     (how many pixels of the benchmark frames that is: DESIGN.md section 3, counted on the GPU).  A
+ *                                     quarter to a third fewer path segments.
+ *   RMD_RENDER_TRACE_BLACK_PATHS      never end a path early, grid or not (measurement and tests: the reference's full segment count).
+ * END and TRACE together are refused (RMD_ERR_INVALID_ARGUMENT).  The rule itself: tests/test_gpu_parity.py::test_black_path_modes_*. */
+#define RMD_RENDER_TRACE_BLACK_PATHS 2u
+#define RMD_RENDER_END_BLACK_PATHS 4u
 typedef struct rmd_settings {
 	uint32_t bounce_limit; /* Settings.bounce_limit; trace() starts at depth 1 (:200,:235) */
 	uint32_t sample_begin; /* first sample index s of this pass                             */
 	uint32_t sample_count; /* number of consecutive samples to add per pixel               */
-	uint32_t flags;        /* 0, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS                  */
+	uint32_t flags;        /* 0 or RMD_RENDER_DOF | one of RMD_RENDER_{TRACE,END}_BLACK_PATHS   */
 	uint64_t seed; /* Philox key; see "RNG" below                                   */
 } rmd_settings;
 
@@ -158,9 +170,10 @@ typedef struct rmd_tile_rect {
  *                           depth, the preceding depth's block afterwards).  r only decides diffuse against specular: it is compared
  *                           with prob_d, which is 0.5 for Diffuse and 0.0 for Metal (:263-264), and for those two values a 22-bit
  *                           uniform gives exactly the probabilities a 53-bit one does.  Taking it from the previous block makes a
- *                           hit's lobe known when the hit is: a diffuse bounce off a black surface ends its path (see
- *                           RMD_RENDER_TRACE_BLACK_PATHS) without the depth's block ever being drawn.  (ABI 2; ABI 1 took r from
- *                           the depth's own block: same distribution, different samples.)
+ *                           hit's lobe known when the hit is: a diffuse bounce off a black surface can end its path (see
+ *                           RMD_RENDER_END_BLACK_PATHS) without the depth's block ever being drawn.  (Since ABI 2; ABI 1 took r from
+ *                           the depth's own block: same distribution, different samples.  ABI 3 changed no sample, only which
+ *                           rmd_settings.flags value ends black paths in scenes with grids.)
  * (One Philox evaluation per path segment, and no RNG state beyond a block counter and those 22 bits.)
  */
 
@@ -237,6 +250,16 @@ rmd_status rmd_render_tiles_host(rmd_context *ctx, const rmd_scene *scene, const
 /* Duration of the most recent render kernel on this context, from HIP events
  * recorded on the context's stream around the launch (valid after a sync). */
 rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms);
+/* How the most recent render on this context was launched (tests assert that a comparison exercised the instantiation they mean). */
+typedef struct rmd_launch_info {
+	uint32_t passes;          /* launches of the render kernel (the per-sample scratch may force several)                           */
+	uint32_t split_k;         /* work items per wave tile of the last pass; > 1 = pooled (pixel, sample) hand-out + ordered sum    */
+	uint32_t persistent;      /* 1 = persistent workgroups drawing work items from a counter, 0 = one wave per work item           */
+	uint32_t end_black_paths; /* 1 = zero-throughput paths were ended (see RMD_RENDER_END_BLACK_PATHS)                             */
+	uint32_t has_grid;        /* 1 = the grid instantiation (wave-cooperative DDA walk) ran                                         */
+	uint32_t _pad[3];
+} rmd_launch_info;
+rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out);
 
 /* ---- output stage (TaskHandle::await src/trace.rs:93-99, cli_old/src/main.rs:155-181) ---- */
 /* out_rgb8[i] = trunc(255 * (1 - exp(-(accum[i]/sample_count) * exposure))^(1/gamma)); device in, host out.  A pixel with a channel that is
@@ -247,7 +270,10 @@ rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32
 
 /* ---- multi-GPU (no reference counterpart; the reference has no collectives) ---- */
 #define RMD_COMM_ID_BYTES 128
-/* rank 0 calls rmd_comm_unique_id and ships the 128 bytes to the other ranks by any means. */
+/* One process per GPU.  rank 0 calls rmd_comm_unique_id and ships the 128 bytes to the other ranks by any means.
+ * Environment: RCCL shares buffers between the ranks through HIP IPC; on hosts whose driver supports dmabuf IPC only, every rank needs
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment BEFORE its first HIP call.  The library sets it (without overwriting a value the caller
+ * chose) when it is loaded; a process that has already made HIP calls by then must export it itself. */
 rmd_status rmd_comm_unique_id(uint8_t id_out[RMD_COMM_ID_BYTES]);
 rmd_status rmd_comm_create(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES], int32_t rank, int32_t world_size,
                            rmd_comm **out);

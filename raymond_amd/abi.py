@@ -7,7 +7,7 @@ compiled library.
 """
 import ctypes as C
 
-RMD_ABI_VERSION = 2
+RMD_ABI_VERSION = 3
 
 RMD_OK = 0
 RMD_ERR_INVALID_ARGUMENT = 1
@@ -36,7 +36,8 @@ RMD_MAT_DIFFUSE, RMD_MAT_METAL, RMD_MAT_EMISSION = 0, 1, 2
 
 RMD_MAX_BOUNCE_LIMIT = 16
 RMD_RENDER_DOF = 1  # rmd_settings.flags
-RMD_RENDER_TRACE_BLACK_PATHS = 2
+RMD_RENDER_TRACE_BLACK_PATHS = 2  # never end a zero-throughput path early
+RMD_RENDER_END_BLACK_PATHS = 4  # end them in scenes with grids too (flags 0: only where provably exact, i.e. scenes without grids)
 (RMD_TUNE_SAMPLE_SPLIT, RMD_TUNE_WALK_BATCH, RMD_TUNE_MASK_BUDGET, RMD_TUNE_LAUNCH_FORM, RMD_TUNE_SCRATCH_CAP_MB) = range(5)
 RMD_LAUNCH_AUTO, RMD_LAUNCH_PER_ITEM, RMD_LAUNCH_PERSISTENT = range(3)
 RMD_COMM_ID_BYTES = 128
@@ -107,4 +108,15 @@ class TileRect(C.Structure):
         ("top", C.c_uint32),
         ("width", C.c_uint32),
         ("height", C.c_uint32),
+    ]
+
+
+class LaunchInfo(C.Structure):  # rmd_launch_info
+    _fields_ = [
+        ("passes", C.c_uint32),
+        ("split_k", C.c_uint32),
+        ("persistent", C.c_uint32),
+        ("end_black_paths", C.c_uint32),
+        ("has_grid", C.c_uint32),
+        ("_pad", C.c_uint32 * 3),
     ]

@@ -125,6 +125,9 @@ rmd_status check_render_args(rmd_context *ctx, const rmd_scene *scene, const rmd
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: backbuffer size must be 1..65535 per axis");
 	if (st->bounce_limit > RMD_MAX_BOUNCE_LIMIT) return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: bounce_limit above RMD_MAX_BOUNCE_LIMIT");
 	if ((uint64_t)st->sample_begin + st->sample_count > 0xFFFFFFFFull) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: sample range overflows u32");
+	if (st->flags & ~(RMD_RENDER_DOF | RMD_RENDER_TRACE_BLACK_PATHS | RMD_RENDER_END_BLACK_PATHS)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: unknown bits in rmd_settings.flags");
+	if ((st->flags & RMD_RENDER_TRACE_BLACK_PATHS) && (st->flags & RMD_RENDER_END_BLACK_PATHS))
+		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: RMD_RENDER_TRACE_BLACK_PATHS and RMD_RENDER_END_BLACK_PATHS exclude each other");
 	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, 1) > rmd::kLdsBudgetBytes)
 		return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: object table + grid masks exceed the 160 KiB LDS of a CU");
 	return RMD_OK;
@@ -161,7 +164,9 @@ RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const r
 	P.mask_words_total = scene ? scene->mask_words_total : 0;
 	P.key0 = (uint32_t)st->seed, P.key1 = (uint32_t)(st->seed >> 32);
 	P.use_dof = ((st->flags & RMD_RENDER_DOF) && cam->aperture_radius > 0.0) ? 1u : 0u; // off by default, as in the reference's loop (:199)
-	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : 1u;
+	// flags 0 = reference-identical: zero-throughput paths are ended only where that provably changes no sample — a scene without grids
+	// (its one NaN source, the interpolated normal of a mesh hit, does not exist there); END opts in for scenes with grids, TRACE never ends
+	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : ((st->flags & RMD_RENDER_END_BLACK_PATHS) || !scene || scene->n_grids == 0u) ? 1u : 0u;
 	P.walk_batch = rmd::kWalkBatchDefault;
 	if (ctx && ctx->tunable[RMD_TUNE_WALK_BATCH] > 0) P.walk_batch = (uint32_t)ctx->tunable[RMD_TUNE_WALK_BATCH]; // any value gives the same image
 #if RMD_DIAG
@@ -501,6 +506,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			per_pass = per_pass / 2u < 8u ? 8u : per_pass / 2u;
 		}
 	}
+	ctx->last_launch = rmd_launch_info{};
+	ctx->last_launch.end_black_paths = P.end_black_paths, ctx->last_launch.has_grid = scene->n_grids != 0u;
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
 	for (uint64_t done = 0; done < settings->sample_count || done == 0; done += per_pass) { // 64-bit: sample_count may be close to 2^32
 		rmd::RenderParams Q = P;
@@ -528,6 +535,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			Q.tile_done = ctx->d_tile_done;
 		}
 		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent_pass ? ctx->n_cus : 0u));
+		ctx->last_launch.passes++, ctx->last_launch.split_k = Q.split_k, ctx->last_launch.persistent = persistent_pass ? 1u : 0u;
 		if (settings->sample_count == 0) break;
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -600,6 +608,12 @@ rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms) {
 	if (!ctx->timed) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_last_kernel_ms: no render has been enqueued on this context");
 	RMD_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
 	RMD_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
+	return RMD_OK;
+}
+
+rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out) {
+	if (!ctx || !out) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_last_launch_info: null argument");
+	*out = ctx->last_launch;
 	return RMD_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -24,6 +25,13 @@ struct rmd_comm {
 };
 
 namespace {
+
+// RCCL shares device buffers between the ranks of a node through HIP IPC.  On hosts whose driver offers dmabuf IPC only (this pool's: without
+// it ncclCommInitRank fails with `hipIpcGetMemHandle: invalid argument`) the HSA runtime must see HSA_ENABLE_IPC_MODE_LEGACY=0 — and it reads
+// its environment once, at the process's first HIP call.  Loading this library is normally earlier than that, so the variable is given its
+// value here UNLESS the caller has set one (no overwrite); a process that makes HIP calls before it loads the library exports it itself
+// (include/raymond_hip.h, rmd_comm_create).
+__attribute__((constructor)) void rmd_default_ipc_mode() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", /*overwrite=*/0); }
 
 struct Rccl {
 	void *handle = nullptr;

@@ -10,7 +10,11 @@
 #define RMD_DEV __device__ __forceinline__
 // measured micro-optimisations, each bit-exact; the switches exist for tools/ab_multi.sh
 #ifndef RMD_OPT_BITOP3
-#define RMD_OPT_BITOP3 1
+#if defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
+#define RMD_OPT_BITOP3 1 // v_bitop3_b32 exists on gfx950 only (the host pass just parses the builtin)
+#else
+#define RMD_OPT_BITOP3 0 // `make ARCH=...` for another target: the two-XOR form, bit-identical
+#endif
 #endif
 #ifndef RMD_OPT_SHARED_SQRT
 #define RMD_OPT_SHARED_SQRT 1

@@ -92,7 +92,7 @@ struct RenderParams {
 	unsigned long long *debug_counters; // 16 counters, only touched when debug_flags & 8
 	uint32_t *work_counter;             // persistent launches: the next work item (zeroed by the host before the launch)
 	uint32_t *tile_done;                // split launches: finished waves per wave tile (zeroed by the host); the last one adds the tile's samples
-	uint32_t end_black_paths;           // 1 (unless rmd_settings.flags has RMD_RENDER_TRACE_BLACK_PATHS): a path whose throughput is exactly (0, 0, 0) is ended
+	uint32_t end_black_paths;           // 1: a path whose throughput is exactly (0, 0, 0) is ended — scenes without grids unless RMD_RENDER_TRACE_BLACK_PATHS, scenes with grids only with RMD_RENDER_END_BLACK_PATHS (api.cpp: make_params)
 	uint32_t _pad_params;
 };
 

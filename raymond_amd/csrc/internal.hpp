@@ -42,6 +42,7 @@ struct rmd_context {
 	// context is created; none of them changes a result.
 	int64_t tunable[RMD_TUNE_COUNT] = {};
 	uint32_t debug_flags = 0; // RMD_DEBUG, honoured by DIAG builds only
+	rmd_launch_info last_launch = {}; // rmd_last_launch_info
 };
 
 struct rmd_scene {

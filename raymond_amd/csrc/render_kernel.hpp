@@ -334,6 +334,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			alive = prim || has_ray || to_shade;
 			if (__ballot(alive) == 0ull) {
 				if (next_item >= pool_items) break;
+				complete = false, cut = false, lens_failed = false; // (C) has consumed them: the next pass through it must not classify a hit twice
 				continue; // a handout that fell entirely on slots outside the tile
 			}
 		} else {

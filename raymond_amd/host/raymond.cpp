@@ -162,7 +162,7 @@ void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene
 		cam.backbuffer_width = (uint32_t)W, cam.backbuffer_height = (uint32_t)H, cam.fov_vert = st.camera_settings.fov_vert;
 		for (int a = 0; a < 3; a++) cam.position[a] = st.camera_settings.transform.position[a];
 		cam.focal_length = st.camera_settings.focal_length, cam.aperture_radius = st.camera_settings.aperture_radius;
-		const uint32_t flags = st.use_dof ? RMD_RENDER_DOF : 0u; // the reference's loop is pinhole-only (:199); the thin lens is opt-in
+		const uint32_t flags = (st.use_dof ? RMD_RENDER_DOF : 0u) | (st.end_black_paths ? RMD_RENDER_END_BLACK_PATHS : 0u); // 0 = the reference's loop: pinhole (:199), every sample identical
 		std::vector<double> host(W * H * 3);
 		const size_t step = st.samples_per_iteration ? st.samples_per_iteration : st.sample_count;
 		for (;;) {

@@ -119,6 +119,8 @@ struct Settings { // src/trace.rs:42-55 (+ the RNG seed the reference lacks)
 	size_t bounce_limit = 5;
 	uint64_t seed = 0x5EED0001ull;
 	bool use_dof = false; // opt-in: generate_primary_ray_with_dof (src/trace.rs:335-360); the reference's loop never calls it (:199)
+	// opt-in (raymond_hip.h: RMD_RENDER_END_BLACK_PATHS): end zero-throughput paths in scenes with meshes too; false = reference-identical
+	bool end_black_paths = false;
 };
 
 struct Tile { // core/src/tile.rs:7-14

@@ -48,6 +48,7 @@ SIGNATURES = {
         [_vp, _vp, _P(abi.Camera), _P(abi.Settings), _P(abi.TileRect), C.c_uint32, _vp],
     ),
     "rmd_last_kernel_ms": (C.c_int32, [_vp, _P(C.c_float)]),
+    "rmd_last_launch_info": (C.c_int32, [_vp, _P(abi.LaunchInfo)]),
     "rmd_resolve_tonemap": (
         C.c_int32,
         [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp],

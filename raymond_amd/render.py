@@ -61,6 +61,12 @@ class Context:
     def synchronize(self):
         self.check(self.L.rmd_context_synchronize(self.handle))
 
+    def last_launch_info(self):
+        """rmd_last_launch_info: how the most recent render was launched (passes, split_k, persistent, end_black_paths, has_grid)."""
+        info = abi.LaunchInfo()
+        self.check(self.L.rmd_last_launch_info(self.handle, C.byref(info)))
+        return info
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self.check(self.L.rmd_last_kernel_ms(self.handle, C.byref(ms)))

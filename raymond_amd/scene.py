@@ -243,7 +243,7 @@ class Settings:
     """src/trace.rs:42-55 plus the RNG seed the reference lacks."""
 
     def __init__(self, camera_settings, sample_count, tile_size=(32, 32), bounce_limit=5, samples_per_iteration=0,
-                 worker_count=None, seed=0x5EED0001, use_dof=False, trace_black_paths=False):
+                 worker_count=None, seed=0x5EED0001, use_dof=False, trace_black_paths=False, end_black_paths=False):
         self.camera_settings = camera_settings
         self.sample_count = int(sample_count)
         self.tile_size = (int(tile_size[0]), int(tile_size[1]))
@@ -254,9 +254,11 @@ class Settings:
         # The reference's loop always calls the pinhole generate_primary_ray (src/trace.rs:199) whatever
         # camera_settings.aperture_radius holds; use_dof=True opts into generate_primary_ray_with_dof (:335-360).
         self.use_dof = bool(use_dof)
-        # By default a path whose throughput has become exactly (0, 0, 0) is ended (its sample is zero in the reference too);
-        # trace_black_paths=True keeps tracing it, which reproduces the reference's 0 x NaN samples on meshes (raymond_hip.h).
+        # A path whose throughput has become exactly (0, 0, 0) (raymond_hip.h: RMD_RENDER_*_BLACK_PATHS).  Default: reference-identical —
+        # ended in scenes without grids (provably the same samples), traced on in scenes with a grid (a later mesh vertex may make the
+        # reference's sample 0 x NaN = NaN).  end_black_paths=True ends them in grid scenes too; trace_black_paths=True never ends one.
         self.trace_black_paths = bool(trace_black_paths)
+        self.end_black_paths = bool(end_black_paths)
 
     def pod(self, sample_begin=0, sample_count=None):
         s = abi.Settings()
@@ -264,7 +266,8 @@ class Settings:
         s.sample_begin = int(sample_begin)
         s.sample_count = self.sample_count if sample_count is None else int(sample_count)
         s.seed = self.seed
-        s.flags = (abi.RMD_RENDER_DOF if self.use_dof else 0) | (abi.RMD_RENDER_TRACE_BLACK_PATHS if self.trace_black_paths else 0)
+        s.flags = ((abi.RMD_RENDER_DOF if self.use_dof else 0) | (abi.RMD_RENDER_TRACE_BLACK_PATHS if self.trace_black_paths else 0)
+                   | (abi.RMD_RENDER_END_BLACK_PATHS if self.end_black_paths else 0))
         return s
 
 

@@ -65,6 +65,7 @@ int main(void) {
   S(rmd_camera); O(rmd_camera, fov_vert); O(rmd_camera, position); O(rmd_camera, focal_length); O(rmd_camera, aperture_radius);
   S(rmd_settings); O(rmd_settings, sample_begin); O(rmd_settings, sample_count); O(rmd_settings, flags); O(rmd_settings, seed);
   S(rmd_tile_rect); O(rmd_tile_rect, height);
+  S(rmd_launch_info); O(rmd_launch_info, split_k); O(rmd_launch_info, persistent); O(rmd_launch_info, end_black_paths); O(rmd_launch_info, has_grid);
   return 0; }
 """
     with tempfile.TemporaryDirectory() as d:
@@ -74,7 +75,7 @@ int main(void) {
         lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
     c_layout = dict((l.split()[0], int(l.split()[1])) for l in lines if l.strip())
     py = {"rmd_material": abi.Material, "rmd_object": abi.Object, "rmd_grid_desc": abi.GridDesc, "rmd_camera": abi.Camera,
-          "rmd_settings": abi.Settings, "rmd_tile_rect": abi.TileRect}
+          "rmd_settings": abi.Settings, "rmd_tile_rect": abi.TileRect, "rmd_launch_info": abi.LaunchInfo}
     for key, val in c_layout.items():
         if "." in key:
             t, f = key.split(".")
@@ -120,7 +121,7 @@ def test_product_package_never_touches_the_oracle():
 
 def test_header_constants_match_the_python_mirror():
     """Flags, tunable keys and the ABI version of include/raymond_hip.h as the C compiler sees them == raymond_amd/abi.py; and Settings
-    builds rmd_settings.flags from them (the thin lens and the trace-everything switch are both opt-in: flags 0 is the default)."""
+    builds rmd_settings.flags from them (the thin lens and both black-path switches are opt-in: flags 0, the reference-identical mode, is the default)."""
     from raymond_amd import scenes
     from raymond_amd.scene import Settings
 
@@ -128,7 +129,7 @@ def test_header_constants_match_the_python_mirror():
 #include <stdio.h>
 #include "raymond_hip.h"
 int main(void) {
-  printf("%u %u %u %u %u %u %u %u %u\n", RMD_ABI_VERSION, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS, (unsigned)RMD_TUNE_SAMPLE_SPLIT, (unsigned)RMD_TUNE_WALK_BATCH,
+  printf("%u %u %u %u %u %u %u %u %u %u\n", RMD_ABI_VERSION, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS, RMD_RENDER_END_BLACK_PATHS, (unsigned)RMD_TUNE_SAMPLE_SPLIT, (unsigned)RMD_TUNE_WALK_BATCH,
          (unsigned)RMD_TUNE_MASK_BUDGET, (unsigned)RMD_TUNE_LAUNCH_FORM, (unsigned)RMD_TUNE_SCRATCH_CAP_MB, (unsigned)RMD_TUNE_COUNT);
   return 0; }
 """
@@ -137,9 +138,10 @@ int main(void) {
         open(c, "w").write(src)
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
-    assert got == [abi.RMD_ABI_VERSION, abi.RMD_RENDER_DOF, abi.RMD_RENDER_TRACE_BLACK_PATHS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_WALK_BATCH,
+    assert got == [abi.RMD_ABI_VERSION, abi.RMD_RENDER_DOF, abi.RMD_RENDER_TRACE_BLACK_PATHS, abi.RMD_RENDER_END_BLACK_PATHS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_WALK_BATCH,
                    abi.RMD_TUNE_MASK_BUDGET, abi.RMD_TUNE_LAUNCH_FORM, abi.RMD_TUNE_SCRATCH_CAP_MB, 5]
     cam = scenes.camera(64, 48, aperture_radius=0.5)
     assert Settings(cam, 4).pod().flags == 0
     assert Settings(cam, 4, use_dof=True).pod().flags == abi.RMD_RENDER_DOF
     assert Settings(cam, 4, use_dof=True, trace_black_paths=True).pod().flags == (abi.RMD_RENDER_DOF | abi.RMD_RENDER_TRACE_BLACK_PATHS)
+    assert Settings(cam, 4, end_black_paths=True).pod().flags == abi.RMD_RENDER_END_BLACK_PATHS

@@ -147,3 +147,48 @@ def test_bench_starts_its_own_ranks_without_touching_the_gpu_in_the_parent():
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]  # both ranks ran bench.py's main()
     assert "{" not in r.stdout  # no JSON line from a run that measured nothing
+
+
+@pytest.mark.parametrize("form", ["self-launch", "under-a-launcher"])
+def test_every_rank_gets_the_dmabuf_ipc_setting_in_both_launch_forms(form):
+    """RCCL on this pool needs HSA_ENABLE_IPC_MODE_LEGACY=0 in every rank before its first HIP call (the driver only supports dmabuf IPC).
+    bench.py sets it (setdefault) at the top of every rank's main() — whether the ranks were started by `python bench.py --gpus 2` itself or
+    by the driver's `python -m torch.distributed.run ... bench.py --gpus 2` — and never overrides a value the environment already holds.
+    RMD_BENCH_ECHO_ENV makes a rank print what it holds and return before it touches torch or a GPU."""
+    import json
+    import subprocess
+
+    for preset in (None, "1"):
+        env = dict(os.environ, RMD_BENCH_ECHO_ENV="1")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY"):
+            env.pop(k, None)
+        if preset is not None:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = preset
+        if form == "self-launch":
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                   str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        echoed = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        assert sorted(e["rank"] for e in echoed) == ["0", "1"], r.stdout
+        assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == (preset or "0") for e in echoed), echoed
+
+
+def test_the_library_sets_the_ipc_mode_when_it_is_loaded_unless_the_caller_did():
+    """libraymond_hip.so's load-time default for C-ABI callers that use rmd_comm_* (csrc/comm.cpp): HSA_ENABLE_IPC_MODE_LEGACY=0, no overwrite."""
+    import subprocess
+
+    from raymond_amd import lib
+
+    # (os.environ is a snapshot taken at interpreter start: read the C environment)
+    code = ("import ctypes; ctypes.CDLL(%r); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print(libc.getenv(b'HSA_ENABLE_IPC_MODE_LEGACY').decode())" % lib.LIB_PATH)
+    for preset, want in ((None, "0"), ("1", "1")):
+        env = dict(os.environ)
+        env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+        if preset is not None:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = preset
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0 and r.stdout.strip() == want, (r.stdout, r.stderr[-500:])

@@ -50,6 +50,46 @@ def test_spot_samples_against_the_oracle(gpu_ctx, oracle, dragon, config):
     assert (dpo == 1).any(axis=1).mean() > 0.25  # the mesh is on a good share of these paths
 
 
+@pytest.mark.parametrize("config,spp,mode", [("C2", 64, "default"), ("C3", 16, "default"), ("C3", 16, "end"), ("C4", 16, "end"), ("C5", 8, "end")])
+def test_spot_pixels_of_the_production_kernel_at_full_size(gpu_ctx, oracle, dragon, config, spp, mode):
+    """Every BASELINE.json configuration at ITS OWN frame size through `rmd_render_tiles` — the production instantiation: persistent
+    workgroups, a tile's samples split over several work items, pooled (pixel, sample) hand-out, per-sample scratch, ordered sum; asserted
+    through rmd_last_launch_info — against the oracle: 320 spot pixels, all samples each, equal the oracle's sequential sums
+    (src/trace.rs:203) to 1e-9.  "default" = rmd_settings.flags 0, the reference-identical mode (C2: zero-throughput paths ended, the scene
+    has no grid; C3: traced on); "end" = RMD_RENDER_END_BLACK_PATHS, the opt-in that ends them on the mesh scenes too (C4 / C5 with flags 0
+    are test_c4_shaped_launch and test_c5_thin_lens_at_full_size_in_tile_mode)."""
+    st = scenes.config_settings(config, spp=spp)
+    st.end_black_paths = mode == "end"
+    cam = st.camera_settings
+    W, H = cam.backbuffer_width, cam.backbuffer_height
+    sc = scenes.reflective_spheres() if config == "C2" else dragon
+    tiles = generate_tiles(W, H, st.tile_size)
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+    info = gpu_ctx.last_launch_info()
+    assert info.split_k > 1 and info.persistent == 1 and info.passes == 1, (info.split_k, info.persistent, info.passes)
+    assert info.has_grid == (0 if config == "C2" else 1) and info.end_black_paths == (1 if config == "C2" or mode == "end" else 0)
+    full = fb.download()
+    fb.close(), ds.close()
+    rng = np.random.default_rng(17)
+    n = 320
+    px = np.stack([rng.integers(int(0.25 * W), int(0.75 * W), n), rng.integers(int(0.25 * H), int(0.9 * H), n)], axis=1)
+    px[: n // 4] = np.stack([rng.integers(0, W, n // 4), rng.integers(0, H, n // 4)], axis=1)
+    xy = np.repeat(px, spp, axis=0).astype(np.uint32)
+    smp = np.tile(np.arange(spp, dtype=np.uint32), n)
+    o = oracle.OracleScene(sc).trace_samples(cam, st, xy, smp).reshape(n, spp, 3)
+    acc = np.zeros((n, 3))
+    for k in range(spp):
+        acc = acc + o[:, k]  # in sample order
+    got = full[px[:, 1], px[:, 0]]
+    ok = rel_close(got, acc, 1e-9).all(axis=1)
+    assert ok.mean() >= 0.99, ok.mean()
+    assert (acc > 0).any(axis=1).mean() > 0.5  # not a comparison of zeros
+    # a pixel that is off is off by whole flipped samples (an ulp-level difference changing a hit sequence), not by garbage
+    assert np.abs(got - acc)[~ok].max(initial=0.0) <= spp * 1.5 * 4
+
+
 def test_full_frame_properties_1080p(gpu_ctx, dragon):
     """1920x1080, 2 spp on the mesh scene: (a) 8 round-robin tile shards sum to the full frame bit for bit (the 8-GPU
     reduce in miniature), (b) 1+1 spp in two launches == 2 spp in one, (c) every pixel finite and non-negative,

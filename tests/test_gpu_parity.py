@@ -458,33 +458,100 @@ def test_config1_image(gpu_ctx, oracle):
     ds.close()
 
 
-def test_ending_black_paths_changes_no_sample(gpu_ctx, oracle, small_mesh_scene):
-    """By default a path whose throughput has become exactly (0, 0, 0) — a diffuse bounce off a black wall, a GGX sample below the surface — is
-    ended: trace() multiplies whatever the rest of the path finds by that zero, so the sample is zero in the reference too.  The frame
-    must equal, bit for bit, the one RMD_RENDER_TRACE_BLACK_PATHS gives (every segment traced, as the reference does) and the oracle's
-    — wherever the reference's sample is finite: a pixel may only differ where tracing on met a non-finite radiance (0 x NaN)."""
-    from raymond_amd.scene import Material, Object, Plane, Scene, Sphere
+def _render_modes(gpu_ctx, sc, W, H, spp, bounces, seed, modes):
+    """{mode: frame} for rmd_settings.flags = 0 ("default"), RMD_RENDER_END_BLACK_PATHS ("end"), RMD_RENDER_TRACE_BLACK_PATHS ("trace")."""
+    tiles = generate_tiles(W, H, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    frames = {}
+    for mode in modes:
+        st = Settings(scenes.camera(W, H), sample_count=spp, bounce_limit=bounces, seed=seed, trace_black_paths=mode == "trace", end_black_paths=mode == "end")
+        fb.zero()
+        render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
+        frames[mode] = fb.download()
+    fb.close(), ds.close()
+    return frames, st, tiles
 
-    cases = [(scenes.reflective_spheres(), 203, 117, 24, 5), (small_mesh_scene, 160, 96, 12, 8)]
-    for sc, W, H, spp, bounces in cases:
-        tiles = generate_tiles(W, H, (32, 32))
-        ds = render.DeviceScene(gpu_ctx, sc)
-        fb = render.Framebuffer(gpu_ctx, W, H)
-        frames = {}
-        for trace_on in (False, True):
-            st = Settings(scenes.camera(W, H), sample_count=spp, bounce_limit=bounces, seed=41, trace_black_paths=trace_on)
-            fb.zero()
-            render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
-            frames[trace_on] = fb.download()
-        same = (frames[False] == frames[True]).all(axis=2)
-        assert np.isfinite(frames[True][~same]).all(axis=1).sum() == 0, "a finite pixel changed"
-        assert same.mean() > 0.9999 and np.isfinite(frames[False]).all()
-        ref = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=4)
-        ok = rel_close(frames[False], ref, 1e-9).all(axis=2)
-        assert ok.mean() >= 0.995
-        # and it is a large share of the work: the black back and side walls end a third of the paths early
-        assert (frames[False] == 0.0).all(axis=2).mean() < 0.5  # (the frame itself is not black)
-        fb.close(), ds.close()
+
+def same_bits(a, b):
+    return (np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+
+
+def test_black_path_modes_change_no_finite_sample(gpu_ctx, oracle, small_mesh_scene):
+    """A path whose throughput has become exactly (0, 0, 0) — a diffuse bounce off a black wall, a GGX sample below the surface — may be ended:
+    trace() multiplies whatever the rest of the path finds by that zero (src/trace.rs:281-282, :315-318), so the sample is zero in the
+    reference too unless a later vertex is non-finite.  Scenes WITHOUT a grid have no such vertex: flags 0 ends those paths there and the
+    frame must equal, bit for bit, the one RMD_RENDER_TRACE_BLACK_PATHS gives (every segment traced) and the oracle's.  Scenes WITH a grid:
+    flags 0 traces on (identical to TRACE by construction — checked), and the opt-in RMD_RENDER_END_BLACK_PATHS may only differ where the
+    traced-on frame is non-finite."""
+    frames, st, tiles = _render_modes(gpu_ctx, scenes.reflective_spheres(), 203, 117, 24, 5, 41, ("default", "trace"))
+    assert same_bits(frames["default"], frames["trace"]).all() and np.isfinite(frames["default"]).all()
+    ref = oracle.OracleScene(scenes.reflective_spheres()).render_tiles(st.camera_settings, st, tiles, threads=4)
+    assert rel_close(frames["default"], ref, 1e-9).all(axis=2).mean() >= 0.995
+    assert (frames["default"] == 0.0).all(axis=2).mean() < 0.5  # (the frame itself is not black)
+
+    frames, st, tiles = _render_modes(gpu_ctx, small_mesh_scene, 160, 96, 12, 8, 41, ("default", "trace", "end"))
+    assert same_bits(frames["default"], frames["trace"]).all()
+    same = same_bits(frames["end"], frames["default"]).all(axis=2)
+    assert np.isfinite(frames["default"][~same]).all(axis=1).sum() == 0, "a finite pixel changed"
+    assert same.mean() > 0.9999
+    ref = oracle.OracleScene(small_mesh_scene).render_tiles(st.camera_settings, st, tiles, threads=4)
+    assert rel_close(frames["default"], ref, 1e-9).all(axis=2).mean() >= 0.995
+
+
+def nan_normal_scene(n=6, every=2):
+    """cli_old's room with a small mesh in the dragon's place, every second triangle of which has vertex normals (0, 0, 0): the interpolated
+    normal of a hit on it is normalize(0) = 0 * (1 / 0) = NaN (triangle.rs:60-67, cgmath normalize) — the non-finite vertex that a real mesh
+    produces once in ~1e9 samples (Heron's radicand rounding below zero for a hit on an edge), made certain."""
+    from raymond_amd.scene import Mesh
+
+    mesh = scenes.lumpy_sphere_mesh(n)
+    nrm = mesh.tri_nrm.copy()
+    nrm[::every] = 0.0
+    return scenes.mesh_scene(Mesh(mesh.tri_pos, nrm))
+
+
+def test_black_path_modes_on_a_mesh_with_nan_normals(gpu_ctx, oracle):
+    """The case the black-path rule turns on, made certain (production instantiation, tile mode): cli_old's room — black back and side walls —
+    around a mesh half of whose triangles yield a NaN normal.  A camera path that bounces diffusely off a black wall (weight exactly 0) and
+    then meets such a triangle is 0 x NaN = NaN in the reference (src/trace.rs:281-282).
+      flags 0 (and TRACE)  == the oracle, NaN for NaN, finite pixels to 1e-9: the reference-identical mode;
+      END_BLACK_PATHS      finite in those pixels — the sequential sum of the pixel's samples with the NaN ones replaced by zero, which
+                           is what ending the path at its black bounce computes — NaN where a NaN vertex is met with a non-zero
+                           throughput, and bit-identical to flags 0 everywhere else."""
+    sc = nan_normal_scene()
+    W, H, spp = 160, 96, 12
+    frames, st, tiles = _render_modes(gpu_ctx, sc, W, H, spp, 5, 41, ("default", "trace", "end"))
+    osc = oracle.OracleScene(sc)
+    ref = osc.render_tiles(st.camera_settings, st, tiles, threads=4)
+    dflt, end = frames["default"], frames["end"]
+    assert same_bits(dflt, frames["trace"]).all()
+    ref_nan, dflt_nan, end_nan = np.isnan(ref).any(axis=2), np.isnan(dflt).any(axis=2), np.isnan(end).any(axis=2)
+    # flags 0: NaN exactly where the oracle is (up to the < 0.5 % of pixels in which an ulp-level difference changes a hit sequence)
+    assert (ref_nan != dflt_nan).mean() < 0.005
+    assert ref_nan.sum() > 2000, "the scene does not produce the case"
+    both_finite = ~ref_nan & ~dflt_nan
+    assert rel_close(dflt[both_finite], ref[both_finite], 1e-9).all(axis=1).mean() >= 0.995
+    # END: a subset of the NaN pixels stays NaN, > 1000 pixels become finite, nothing else moves
+    assert not (end_nan & ~dflt_nan).any()
+    rescued = dflt_nan & ~end_nan
+    assert rescued.sum() > 1000, "no NaN behind a zero weight in this frame: the test would be vacuous"
+    untouched = ~dflt_nan
+    assert same_bits(end[untouched], dflt[untouched]).all(), "RMD_RENDER_END_BLACK_PATHS changed a pixel that is finite in the reference"
+    assert np.isnan(end[end_nan]).any(axis=1).all() and np.isnan(dflt[end_nan]).any(axis=1).all()
+    # the rescued pixels hold the reference's sample sum with the NaN samples as zeros (oracle per-sample values, added in sample order)
+    ys, xs = np.nonzero(rescued)
+    pick = np.random.default_rng(3).choice(len(ys), size=200, replace=False)
+    xy = np.repeat(np.stack([xs[pick], ys[pick]], axis=1), spp, axis=0).astype(np.uint32)
+    smp = np.tile(np.arange(spp, dtype=np.uint32), len(pick))
+    per_sample = osc.trace_samples(st.camera_settings, st, xy, smp).reshape(len(pick), spp, 3)
+    assert np.isnan(per_sample).any(axis=(1, 2)).all()
+    cleaned = np.where(np.isnan(per_sample).any(axis=2, keepdims=True), 0.0, per_sample)
+    expect = np.zeros((len(pick), 3))
+    for k in range(spp):
+        expect = expect + cleaned[:, k]
+    ok = rel_close(end[ys[pick], xs[pick]], expect, 1e-9).all(axis=1)
+    assert ok.mean() >= 0.97, "rescued pixels do not hold the sum of their finite samples: %d of %d" % ((~ok).sum(), len(ok))
 
 
 def test_output_stage_is_byte_exact_on_adversarial_frames(gpu_ctx, oracle):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/diag_pool.sh SPP — one DIAG=1 build in /tmp; event counters (RMD_DEBUG=8) and per-phase time stamps (16) of the C3 frame with the
+# NEEDS tools/experiments/walk_pool.patch applied.  usage (GPU box, repo root): tools/experiments/diag_pool.sh SPP — one DIAG=1 build in /tmp; event counters (RMD_DEBUG=8) and per-phase time stamps (16) of the C3 frame with the
 # walk pool on and off
 spp=${1:-50}
 rm -rf /tmp/repo_diag && mkdir -p /tmp/repo_diag && cp -r include raymond_amd /tmp/repo_diag/

@@ -1,6 +1,7 @@
-"""Walk pool on / off on the full C3 frame (python tools/pool_ab.py [spp]): kernel time of each, and the frames must be bit-identical."""
+"""Walk pool on / off on the full C3 frame (python tools/experiments/pool_ab.py [spp]): kernel time of each, and the frames must be bit-identical."""
+# NEEDS tools/experiments/walk_pool.patch applied (git apply) and the library rebuilt: the tunable it switches (abi.RMD_TUNE_*) exists only in that patch.
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # tools/experiments/ -> repo root
 from raymond_amd import abi, render, scenes
 from raymond_amd.scene import generate_tiles
 

@@ -1,7 +1,8 @@
-"""The shelf (render_kernel.hpp: ShelfWave) on / off on a full frame: python tools/shelf_ab.py [spp] [workload] — kernel time of each; the frames must be
+"""The shelf (render_kernel.hpp: ShelfWave) on / off on a full frame: python tools/experiments/shelf_ab.py [spp] [workload] — kernel time of each; the frames must be
 bit-identical."""
+# NEEDS tools/experiments/shelf_and_rotation.patch applied (git apply) and the library rebuilt: the tunable it switches (abi.RMD_TUNE_*) exists only in that patch.
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # tools/experiments/ -> repo root
 from raymond_amd import abi, render, scenes
 from raymond_amd.scene import generate_tiles
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc counter CSVs per counter for the render kernel:  pmc_summary.py [--json OUT.json --tag NAME] DIR [DIR...]
 Prints counter totals per dispatch (averaged over the render_kernel dispatches of each pass).  Directory names are
-<WORKLOAD>_<spp>_<sq|fetch|write> (tools/profile_round.sh).  With --json, also writes what bench.py reads:
+<WORKLOAD>[-end|-trace]_<spp>_<sq|fetch|write> (tools/profile_round.sh; the suffix is tools/quick_time.py's flags selector and becomes
+part of the key: "C3" = flags 0, "C3_end" = RMD_RENDER_END_BLACK_PATHS).  Every entry records the hash of the sources it was measured at
+(bench.py: source_hash) so that a later bench line can say when it has gone stale.  With --json, also writes what bench.py reads:
   profiles/pmc_latest.json   per workload: VALU issue occupancy, lane utilisation, wave instructions per sample
   profiles/hbm_traffic.json  per workload: L2<->fabric bytes per launch = 2 x FETCH_SIZE KiB (gfx950 reports half the bytes of
                              16-B/lane loads, MI355X_MICROARCH.md) + WRITE_SIZE KiB, render kernel + sum kernel
@@ -22,13 +24,17 @@ while args and args[0].startswith("--"):
         tag = args[1]
     args = args[2:]
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_hash only; importing bench.py runs nothing)
+
+SRC_HASH = bench.source_hash()
 SAMPLES = {"C2": 1920 * 1080, "C3": 1920 * 1080, "C5": 1920 * 1080, "C4": 3840 * 2160}
 N_SIMD = 256 * 4
 agg = collections.defaultdict(dict)  # (workload, spp) -> counter -> avg per dispatch
 for d in args:
     base = os.path.basename(d.rstrip("/"))
     parts = base.split("_")
-    key = (parts[0], int(parts[1])) if len(parts) >= 3 and parts[1].isdigit() else (parts[0], None)
+    key = (parts[0].replace("-", "_"), int(parts[1])) if len(parts) >= 3 and parts[1].isdigit() else (parts[0].replace("-", "_"), None)
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
@@ -48,9 +54,9 @@ if json_out:
     valu, traffic = {}, {"_how": __doc__.split("With --json")[1].strip()}
     for (wl, spp), c in agg.items():
         if "SQ_INSTS_VALU" in c and spp:
-            n = SAMPLES[wl] * spp
+            n = SAMPLES[wl.split("_")[0]] * spp
             valu[wl] = {
-                "source": tag, "spp": spp,
+                "source": tag, "spp": spp, "source_hash": SRC_HASH, "sq_insts_salu_per_valu": c.get("SQ_INSTS_SALU", 0.0) / c["SQ_INSTS_VALU"],
                 "wave_instr_valu_per_sample": c["SQ_INSTS_VALU"] / n,
                 "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0),
                 # fraction of a wave's resident cycles in which it has a VALU instruction in flight; times the waves resident per
@@ -61,7 +67,7 @@ if json_out:
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             fetch = c["FETCH_SIZE"] + c.get("FETCH_SIZE[sum_kernel]", 0.0)
             write = c["WRITE_SIZE"] + c.get("WRITE_SIZE[sum_kernel]", 0.0)
-            traffic[wl] = {"source": tag, "spp": spp, "bytes_per_launch": 2.0 * fetch * 1024.0 + write * 1024.0,
+            traffic[wl] = {"source": tag, "spp": spp, "source_hash": SRC_HASH, "bytes_per_launch": 2.0 * fetch * 1024.0 + write * 1024.0,
                            "render_fetch_kib": c["FETCH_SIZE"], "render_write_kib": c["WRITE_SIZE"],
                            "sum_fetch_kib": c.get("FETCH_SIZE[sum_kernel]", 0.0), "sum_write_kib": c.get("WRITE_SIZE[sum_kernel]", 0.0)}
     os.makedirs(json_out, exist_ok=True)

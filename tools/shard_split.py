@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raymond_amd import abi, render, scenes, shard
 from raymond_amd.scene import generate_tiles
 name = sys.argv[1]; n = int(sys.argv[2])
