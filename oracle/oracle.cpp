@@ -99,7 +99,8 @@ struct Counters {
 	uint64_t c[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 enum { K_SAMPLES, K_SEGMENTS, K_CELLS, K_TRI_TESTS, K_MESH_HITS, K_BOUNCES, K_DRAWS, K_WALKS, K_OCCUPIED_CELLS /* visited cells that hold a triangle */,
-       K_ZERO_DIFFUSE /* bounces whose weight is exactly zero: diffuse lobe */, K_ZERO_SPECULAR /* ... GGX lobe */, K_COUNT = 12 };
+       K_ZERO_DIFFUSE /* bounces whose weight is exactly zero: diffuse lobe */, K_ZERO_SPECULAR /* ... GGX lobe */,
+       K_RETESTS /* triangle tests of a triangle that the PREVIOUS cell of the same walk listed too (it missed there, so it misses here) */, K_COUNT = 12 };
 std::mutex g_counter_mutex;
 Counters g_counters;
 thread_local Counters tl_counters;
@@ -459,6 +460,7 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 #endif
 	} wstat{w_cells, w_nonempty, w_tests, w_maxc};
 	(void)wstat;
+	[[maybe_unused]] uint64_t prev_cell = ~0ull; /* counters only: the mapping-table run of the cell visited before this one */
 	for (;;) {
 		/* `as usize` of a negative i32 sign-extends; the index arithmetic wraps (release build) */
 		uint64_t x = (uint64_t)(int64_t)cx, y = (uint64_t)(int64_t)cy, z = (uint64_t)(int64_t)cz;
@@ -467,6 +469,16 @@ Hit grid_intersects(const AccGrid &g, const Ray &ray) {
 		ORC_COUNT(K_CELLS, 1);
 		uint64_t cell = g.cells[idx];
 		uint64_t count = g.mapping_table[cell];
+#ifndef ORC_NO_COUNTERS
+		if (prev_cell != ~0ull)
+			for (uint64_t i = 1; i <= count; i++)
+				for (uint64_t j = 1; j <= g.mapping_table[prev_cell]; j++)
+					if (g.mapping_table[prev_cell + j] == g.mapping_table[cell + i]) {
+						ORC_COUNT(K_RETESTS, 1);
+						break;
+					}
+		prev_cell = cell;
+#endif
 		w_cells++, w_tests += count, w_nonempty += count > 0, w_maxc = std::max(w_maxc, count);
 		if (count > 0) ORC_COUNT(K_OCCUPIED_CELLS, 1);
 		double closest = 5712515.0;

@@ -299,34 +299,71 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 			rmd_scene_destroy(sc);
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: grid resolution too large for 31-bit cell indices");
 		}
-		// cell entries + contiguous per-cell triangle runs (device_types.hpp): record = v0, edge1 = v1 - v0, edge2 = v2 - v0
-		// (triangle.rs:16-17, same subtraction, done once), triangle index, pad — in mapping_table order
+		// triangle records, per-cell lists of triangle indices and the cell entries (device_types.hpp): record = v0, edge1 = v1 - v0,
+		// edge2 = v2 - v0 (triangle.rs:16-17, same subtraction, done once); entry slot 0 = the cell's list in mapping_table order, slots 1..6 =
+		// that list without the triangles the cell at index c - delta_s lists too (the cell a walk came from: tested already, missed)
 		const uint64_t n_refs = g.n_mapping - g.n_cells;
 		if (n_refs > 0xFFFFFFFFull) {
 			rmd_scene_destroy(sc);
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: more than 2^32-1 cell->triangle references");
 		}
-		std::vector<rmd::CellEntry> entries(g.n_cells);
-		std::vector<unsigned char> runs((size_t)n_refs * 80u, 0);
-		uint64_t next = 0, last_nonempty = 0;
-		bool any_nonempty = false;
-		for (uint64_t c = 0; c < g.n_cells; c++) {
-			const uint32_t off = g.cells[c], cnt = g.mapping_table[off];
-			entries[c].first = (uint32_t)next, entries[c].count = cnt;
-			if (cnt) last_nonempty = c, any_nonempty = true;
-			for (uint32_t k = 1; k <= cnt; k++) {
-				if (next >= n_refs) { // cells sharing a run: the tables are not the builder's; refuse rather than overflow
+		std::vector<unsigned char> recs((size_t)g.n_tris * rmd::kTriRecStride, 0);
+		for (uint64_t ti = 0; ti < g.n_tris; ti++) {
+			const double *p = g.tri_pos + (size_t)ti * 9;
+			double q[9];
+			for (int a = 0; a < 3; a++) q[a] = p[a], q[3 + a] = p[3 + a] - p[a], q[6 + a] = p[6 + a] - p[a];
+			std::memcpy(recs.data() + (size_t)ti * rmd::kTriRecStride, q, sizeof(q));
+		}
+		std::vector<rmd::CellEntry> entries((size_t)g.n_cells * rmd::kEntrySlots);
+		std::vector<uint32_t> ids;
+		ids.reserve((size_t)n_refs * 3);
+		{
+			uint64_t refs_seen = 0;
+			for (uint64_t c = 0; c < g.n_cells; c++) { // slot 0: the full lists, validated against overlapping runs
+				const uint32_t off = g.cells[c], cnt = g.mapping_table[off];
+				refs_seen += cnt;
+				if (refs_seen > n_refs) { // cells sharing a run: the tables are not the builder's; refuse rather than overflow
 					rmd_scene_destroy(sc);
 					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table runs overlap");
 				}
-				const uint32_t ti = g.mapping_table[off + k];
-				const double *p = g.tri_pos + (size_t)ti * 9;
-				double *q = reinterpret_cast<double *>(runs.data() + (size_t)next * 80u);
-				for (int a = 0; a < 3; a++) q[a] = p[a], q[3 + a] = p[3 + a] - p[a], q[6 + a] = p[6 + a] - p[a];
-				reinterpret_cast<uint32_t *>(q)[18] = ti;
-				next++;
+				entries[c * rmd::kEntrySlots] = rmd::CellEntry{(uint32_t)ids.size(), cnt};
+				ids.insert(ids.end(), g.mapping_table + off + 1, g.mapping_table + off + 1 + cnt);
+			}
+			const int64_t sx = (int64_t)g.resolution[0], sxz = (int64_t)g.resolution[0] * (int64_t)g.resolution[2]; // Q5: res.z where res.y is meant
+			const int64_t delta[7] = {0, 1, -1, sx, -sx, sxz, -sxz};
+			std::vector<uint32_t> fresh;
+			std::vector<uint64_t> listed_by((size_t)g.n_tris, ~0ull); // triangle -> the (cell, slot) pass that last saw it in a predecessor's list
+			for (uint64_t c = 0; c < g.n_cells; c++) {
+				const rmd::CellEntry full = entries[c * rmd::kEntrySlots];
+				const uint32_t *mine = g.mapping_table + g.cells[c] + 1;
+				for (uint32_t s = 1; s < rmd::kEntrySlots; s++) {
+					rmd::CellEntry &e = entries[c * rmd::kEntrySlots + s];
+					e = full;
+					if (s == 7u || full.count == 0u) continue;
+					const int64_t prev = (int64_t)c - delta[s];
+					if (prev < 0 || prev >= (int64_t)g.n_cells || prev == (int64_t)c) continue; // no such predecessor: never asked for
+					const uint32_t poff = g.cells[prev], pcnt = g.mapping_table[poff];
+					if (pcnt == 0u) continue;
+					const uint32_t *theirs = g.mapping_table + poff + 1;
+					fresh.clear();
+					const uint64_t pass = c * rmd::kEntrySlots + s;
+					for (uint32_t j = 0; j < pcnt; j++) listed_by[theirs[j]] = pass;
+					for (uint32_t k = 0; k < full.count; k++)
+						if (listed_by[mine[k]] != pass) fresh.push_back(mine[k]);
+					if (fresh.size() == full.count) continue; // nothing to leave out: shares the full list
+					e = rmd::CellEntry{(uint32_t)ids.size(), (uint32_t)fresh.size()};
+					ids.insert(ids.end(), fresh.begin(), fresh.end());
+					if (ids.size() > 0xFFFFFFFFull) {
+						rmd_scene_destroy(sc);
+						return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: triangle index lists exceed 2^32 entries");
+					}
+				}
 			}
 		}
+		uint64_t last_nonempty = 0;
+		bool any_nonempty = false;
+		for (uint64_t c = 0; c < g.n_cells; c++)
+			if (entries[c * rmd::kEntrySlots].count) last_nonempty = c, any_nonempty = true;
 		// occupancy bitmask for LDS: bit i covers cells [i << shift, (i+1) << shift); only up to the last non-empty cell
 		const uint64_t covered = any_nonempty ? last_nonempty + 1 : 0;
 		size_t budget_bytes = rmd::kMaskBudgetBytes;
@@ -343,15 +380,17 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		const uint64_t bits = covered ? ((covered - 1) >> shift) + 1 : 0;
 		std::vector<uint32_t> mask((size_t)((bits + 31) / 32) + 1, 0u); // + one all-zero word: indices past the mask read it
 		for (uint64_t c = 0; c < covered; c++)
-			if (entries[c].count) mask[(c >> shift) >> 5] |= 1u << ((c >> shift) & 31u);
+			if (entries[c * rmd::kEntrySlots].count) mask[(c >> shift) >> 5] |= 1u << ((c >> shift) & 31u);
 		d.mask_bits = (uint32_t)bits, d.mask_shift = shift, d.mask_n_words = (uint32_t)mask.size();
 		d.mask_lds_word = sc->mask_words_total;
 		sc->mask_words_total += (uint32_t)((mask.size() + 3) & ~(size_t)3);
 		void *p = nullptr;
 		RMD_SCENE_HIP(upload(entries.data(), entries.size() * sizeof(rmd::CellEntry), &p));
 		d.cell_entries = (const rmd::CellEntry *)p;
-		RMD_SCENE_HIP(upload(runs.data(), runs.size(), &p));
-		d.tri_runs = p;
+		RMD_SCENE_HIP(upload(ids.data(), ids.size() * sizeof(uint32_t), &p));
+		d.tri_ids = (const uint32_t *)p;
+		RMD_SCENE_HIP(upload(recs.data(), recs.size(), &p));
+		d.tri_recs = p;
 		RMD_SCENE_HIP(upload(mask.data(), mask.size() * sizeof(uint32_t), &p));
 		d.mask_words = (const uint32_t *)p;
 		RMD_SCENE_HIP(upload(g.tri_pos, g.n_tris * 9 * sizeof(double), &p));
@@ -548,8 +587,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			std::fprintf(stderr, "[rmd stamps, cycles] wave_total=%llu next_ray=%llu simple=%llu walk=%llu classify=%llu | walk: init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
 			             h[0], h[1], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
 		else
-			std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu tests=%llu chunks=%llu | main_iterations=%llu live_lanes=%llu lanes_with_ray=%llu shade_passes=%llu shaded_lanes=%llu\n",
-			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[14], h[13]);
+			std::fprintf(stderr, "[rmd debug] walk_calls=%llu walkers=%llu calls_with_walkers=%llu rounds=%llu wave_steps=%llu lane_steps=%llu test_rounds=%llu tests=%llu chunks=%llu | main_iterations=%llu live_lanes=%llu lanes_with_ray=%llu | stepping iterations with <= 4 / 8 / 16 lanes: %llu / %llu / %llu, with <= 8 lanes while tests wait: %llu\n",
+			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[7], h[13], h[14], h[15]);
 	}
 	return RMD_OK;
 }

@@ -30,14 +30,25 @@ constexpr uint32_t kPairTestedAtPartner = 0x80000000u;
 
 // One AccGrid (reference core/src/geometry/acc_grid.rs:27-33), re-laid out at upload for the wave-cooperative walk
 // (grid_walk.hpp).  `cells[c] -> mapping_table[off] = count, idx...` (acc_grid.rs:67-74) becomes
-//   cell_entries[c] = {first record, count}                       one 8-byte gather per candidate cell
-//   tri_runs[first .. first+count)                                 the cell's triangles as CONTIGUOUS 80-byte records,
-//                                                                  in mapping_table order: v0, edge1, edge2 (9 f64), triangle index (u32), pad
-// so a cell's tests read one coalesced run instead of chasing an index per triangle.  A triangle referenced by k cells
-// is stored k times (HBM is 288 GB; the benchmark mesh needs tens of MB).
+//   tri_recs[t]                      ONE record per triangle: v0, edge1, edge2 (9 f64; kTriRecStride bytes apart) — 8 MB for the 99k-triangle
+//                                    benchmark mesh, where per-cell copies of the records were 60 MB (measured and without effect on the
+//                                    frame time: records renumbered in the order a scan over the cells meets them, and a 72-byte stride;
+//                                    a 128-byte stride is 13 % slower: every lane of a load then reads the same 16 bytes of its line)
+//   tri_ids[..]                      lists of triangle indices, in mapping_table order
+//   cell_entries[c * 8 + s] = {first id, count}     s = 0: every triangle of cell c (a walk's first cell);
+//                                    s = 1 .. 6: the triangles of c that cell c - delta_s does NOT list, delta_s = +1, -1, +res.x, -res.x,
+//                                    +res.x*res.z, -res.x*res.z — the index step by which the DDA entered c (kEntrySlot*).
+// A triangle that the previous cell of a walk listed has been tested against this very ray already and missed (a hit there would have ended
+// the walk, acc_grid.rs:151-153), so it misses again: leaving it out changes no result and removes 22 % of the reference's triangle tests on
+// the benchmark mesh (oracle counter `retests`).  One 8-byte gather per candidate cell, as before; a list equal to the full one shares it.
 struct CellEntry {
 	uint32_t first, count;
 };
+constexpr uint32_t kEntrySlots = 8; // entries per cell (slot 7 unused: a cell's row is one 64-byte line)
+#ifndef RMD_TRI_REC_STRIDE
+#define RMD_TRI_REC_STRIDE 80
+#endif
+constexpr uint32_t kTriRecStride = RMD_TRI_REC_STRIDE; // bytes between triangle records (72 used)
 
 struct alignas(16) DevGrid {
 	double bbox_min[3];
@@ -45,8 +56,9 @@ struct alignas(16) DevGrid {
 	double cell_size[3];
 	uint64_t res[3];
 	uint64_t n_cells;
-	const CellEntry *cell_entries; // n_cells x {first, count}
-	const void *tri_runs;       // n_refs x 80 B
+	const CellEntry *cell_entries; // n_cells x kEntrySlots x {first id, count}
+	const uint32_t *tri_ids;    // the entries' lists of triangle indices
+	const void *tri_recs;       // n_tris x kTriRecStride bytes: v0, edge1, edge2
 	const double *tri_pos;      // n_tris * 9: v0 v1 v2 (Heron normal, triangle.rs:47-68)
 	const double *tri_nrm;      // n_tris * 9: n0 n1 n2
 	const double *tri_aux;      // n_tris * 4: |v0v1|, |v0v2|, Heron area of the triangle, its exact reciprocal or NaN (internal.hpp: triangle_aux)

@@ -8,10 +8,12 @@
 //   1. every lane steps ITS OWN ray's DDA (bit-identical arithmetic, :100-125 and :155-183) but skips empty
 //      cells with an occupancy bitmask held in LDS — no global memory access until a candidate cell — and
 //      collects up to kWalkCand candidate cells per round (it steps past a candidate speculatively);
-//   2. the lanes fetch the 8-byte entries {first record, count} of their candidates together;
+//   2. the lanes fetch the 8-byte entries {first id, count} of their candidates together — of the list that leaves out the triangles
+//      the cell the ray came from lists too (device_types.hpp: they were tested against this ray one cell earlier and missed);
 //   3. all triangle tests of the round — every (lane, candidate, triangle) — are numbered by a prefix sum and
 //      taken by the WHOLE WAVE 64 at a time, one test per lane: the test's ray comes from its owner lane's
-//      registers (ds_bpermute), the cell's triangle records are contiguous 80-byte rows (coalesced), and the
+//      registers (ds_bpermute), its triangle index from the cell's list (neighbouring tests read neighbouring indices), the
+//      triangle's record — one per triangle, 8 MB for the benchmark mesh — by that index, and the
 //      winner is picked by a scalar loop over the hit ballot in ascending (lane, candidate, triangle) order with
 //      a strict '<' — the reference's `if distance < closest` scan (:137-149) exactly, including the 5712515.0
 //      start value and first-wins ties; the earliest candidate cell with an accepted hit wins (:151-153).
@@ -67,18 +69,17 @@ RMD_DEV uint32_t wave_scan_max(uint32_t v) {
 	return v;
 }
 
-// One 80-byte triangle record of a cell run: v0, edge1, edge2, original triangle index.
+// One triangle record (kTriRecStride bytes apart): v0, edge1, edge2.
 struct TriRecord {
 	V3 v0, e1, e2;
-	uint32_t tri;
 };
 RMD_DEV TriRecord load_record(const RMD_GLOBAL unsigned char *p) {
 	const RMD_GLOBAL double *d = reinterpret_cast<const RMD_GLOBAL double *>(p);
 	TriRecord r;
 	r.v0 = ld3(d), r.e1 = ld3(d + 3), r.e2 = ld3(d + 6);
-	r.tri = reinterpret_cast<const RMD_GLOBAL uint32_t *>(p)[18];
 	return r;
 }
+constexpr uint32_t kNoCell = 0xFFFFFFFFu; // "the cell before this one" of a walk's first cell
 
 // One DDA step (acc_grid.rs:155-183) is done inline in the walk loop below.  The same three comparisons select the axis
 // (x if tmx<tmy && tmx<tmz; y if !(tmx<tmy) && tmy<tmz; else z); that axis' t_max advances by its t_delta (same
@@ -110,9 +111,6 @@ constexpr uint32_t kWalkCand = RMD_WALK_CANDIDATES;
 static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 // After its first candidate a lane keeps stepping at most this many cells looking for more (the non-empty cells of
 // one surface crossing are adjacent); further cells wait for the next round.
-#ifndef RMD_WALK_PREFETCH
-#define RMD_WALK_PREFETCH 0 // measured: 111.8 vs 108.8 ms on the 100-spp C3 launch (8 more spilled registers, one more load per chunk)
-#endif
 #ifndef RMD_WALK_ASM_STEP
 #define RMD_WALK_ASM_STEP 1
 #endif
@@ -123,8 +121,9 @@ constexpr uint32_t kWalkLookahead = RMD_WALK_LOOKAHEAD;
 
 // Per-wave LDS scratch of the cooperative triangle tests.  A (lane, candidate slot) pair has the key lane * kWalkCand + slot.
 struct alignas(16) WalkScratch {
-	uint32_t start[64 * kWalkCand]; // by key: number of the pair's first test in the round (exclusive prefix sum of the counts)
-	uint32_t first[64 * kWalkCand]; // by key: first record of the pair's cell run; during the walk, slot m of lane l is parked at [m * 64 + l]
+	uint32_t start[64 * kWalkCand]; // by key: number of the pair's first test in the round (exclusive prefix sum of the counts); during the stepping,
+	                                // the cell BEFORE candidate m of lane l at [m * 64 + l]
+	uint32_t first[64 * kWalkCand]; // by key: first entry of the pair's list in tri_ids; during the stepping, candidate m of lane l at [m * 64 + l]
 	uint32_t marker[64];            // per 64-test chunk: lane + 1 of the lane whose tests begin at that position
 };
 
@@ -195,17 +194,38 @@ struct alignas(16) WalkScratch {
 // the look-ahead of the early lanes no longer overlaps the search of the late ones — 3 % fewer instructions, 3 % more time.)
 template <bool LEAN>
 RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shift, uint32_t mask_pad_bit, uint32_t idx_limit, WalkScratch &scr,
-                                    uint32_t lane, bool &walking, uint32_t &n_cand, uint32_t &idx, uint32_t &remx, uint32_t &remy, uint32_t &remz,
-                                    double &tmx, double &tmy, double &tmz, double tdx, double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz) {
+                                    uint32_t lane, bool &walking, uint32_t &n_cand, uint32_t &idx, uint32_t &prev, uint32_t &remx, uint32_t &remy, uint32_t &remz,
+                                    double &tmx, double &tmy, double &tmz, double tdx, double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz,
+                                    [[maybe_unused]] unsigned long long *dbg = nullptr) {
 	uint32_t budget = 0x7FFFFFFFu;
+#if RMD_DIAG
+	if (dbg) scr.marker[0] = 0u; // DIAG: set once a lane of the wave has a candidate in this round
+#endif
 	while (walking && budget != 0u) {
+#if RMD_DIAG
+		if (dbg) { // occupancy of the stepping loop: iterations, stepping lanes, iterations with few lanes, and of those the ones with test work already waiting
+			const unsigned long long act = __ballot(true);
+			const uint32_t n = (uint32_t)__popcll(act), have = scr.marker[0];
+			if (lane == (uint32_t)__builtin_ctzll(act)) {
+				atomicAdd(&dbg[4], 1ull), atomicAdd(&dbg[5], (unsigned long long)n);
+				if (n <= 4u) atomicAdd(&dbg[7], 1ull);
+				if (n <= 8u) atomicAdd(&dbg[13], 1ull);
+				if (n <= 16u) atomicAdd(&dbg[14], 1ull);
+				if (n <= 8u && have) atomicAdd(&dbg[15], 1ull);
+			}
+		}
+#endif
 		RMD_DDA_ITERATION(LEAN)
 		budget--;
 		if (occupied) {
-			scr.first[n_cand * 64u + lane] = here;
+			scr.first[n_cand * 64u + lane] = here, scr.start[n_cand * 64u + lane] = prev; // the candidate and the cell the ray entered it from
 			n_cand++;
 			budget = n_cand == kWalkCand ? 0u : (budget < kWalkLookahead ? budget : kWalkLookahead);
+#if RMD_DIAG
+			if (dbg) scr.marker[0] = 1u;
+#endif
 		}
+		prev = here;
 	}
 }
 
@@ -214,8 +234,8 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 // most one vector and one scalar instruction per 4 cycles, from different waves, so the loop is as slow as the LONGER of
 // its two streams: the compiler's rendering of the C++ loop has 26 vector + 20 scalar instructions per step (32 + 22 when
 // a candidate is recorded), this one 19 + 17 (22 + 18):
-//   * the lane's cell index is stored to its next candidate slot on EVERY step (an LDS store, neither stream) and the slot
-//     only advances when the cell turns out occupied — no copy of the index from before the step is kept;
+//   * the lane's cell index — and the index of the cell it came from, which selects the candidate's triangle list — is stored to its
+//     next candidate slot on EVERY step (LDS stores, neither stream) and the slot only advances when the cell turns out occupied;
 //   * the exit counters are kept minus one and decremented with v_sub_co: the borrow IS "this axis left the grid"
 //     (acc_grid.rs:158,164,172,178) — no minimum of three, no compare; carry-outs of lanes outside exec are written as 0,
 //     like a compare's, so the three axis blocks' borrows are simply OR-ed;
@@ -228,9 +248,11 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 #ifndef RMD_WALK_ASM_LOOP
 #define RMD_WALK_ASM_LOOP 1
 #endif
+// cand_base: LDS address of this lane's column of WalkScratch::start (the cells before the candidates); the candidates go to the same column
+// of WalkScratch::first, sizeof(start) bytes further on.
 RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bit, uint32_t idx_limit, uint32_t cand_base, bool &walking, uint32_t &n_cand,
-                                             uint32_t &idx, uint32_t &remx, uint32_t &remy, uint32_t &remz, double &tmx, double &tmy, double &tmz, double tdx,
-                                             double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz) {
+                                             uint32_t &idx, uint32_t &prev, uint32_t &remx, uint32_t &remy, uint32_t &remz, double &tmx, double &tmy, double &tmz,
+                                             double tdx, double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz) {
 	uint32_t caddr = cand_base, bit, word, budget, cleft;
 	asm volatile(
 	    "s_mov_b64 s[86:87], exec\n\t"                      /* entry exec */
@@ -247,7 +269,9 @@ RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bi
 	    "v_lshrrev_b32 %[word], 5, %[bit]\n\t"
 	    "v_lshl_add_u32 %[word], %[word], 2, %[mbase]\n\t"
 	    "ds_read_b32 %[word], %[word]\n\t"
-	    "ds_write_b32 %[caddr], %[idx]\n\t"                 /* the cell the lane stands on, into its next candidate slot */
+	    "ds_write_b32 %[caddr], %[idx] offset:%[firstoff]\n\t" /* the cell the lane stands on, into its next candidate slot */
+	    "ds_write_b32 %[caddr], %[prev]\n\t"                /* ... and the cell it came from */
+	    "v_mov_b32 %[prev], %[idx]\n\t"
 	    "v_cmp_lt_f64 s[90:91], %[tmx], %[tmy]\n\t"
 	    "v_cmp_lt_f64 s[92:93], %[tmx], %[tmz]\n\t"
 	    "v_cmp_lt_f64 vcc, %[tmy], %[tmz]\n\t"
@@ -274,7 +298,7 @@ RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bi
 	    "s_or_b64 s[90:91], s[90:91], s[96:97]\n\t"         /* lanes whose walk ended on this step */
 	    "s_or_b64 s[88:89], s[88:89], s[90:91]\n\t"
 	    "s_or_b64 s[90:91], s[90:91], vcc\n\t"              /* the round's stop mask */
-	    "s_waitcnt lgkmcnt(1)\n\t"                          /* the mask word (the store behind it may still be in flight) */
+	    "s_waitcnt lgkmcnt(2)\n\t"                          /* the mask word (the two stores behind it may still be in flight) */
 	    "v_bfe_u32 %[bit], %[word], %[bit], 1\n\t"          /* bit position modulo 32 */
 	    "v_cmp_ne_u32_e32 vcc, 0, %[bit]\n\t"
 	    "s_and_b64 exec, s[94:95], vcc\n\t"
@@ -296,10 +320,10 @@ RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bi
 	    "v_add_u32 %[ry], 1, %[ry]\n\t"
 	    "v_add_u32 %[rz], 1, %[rz]\n\t"
 	    "s_waitcnt lgkmcnt(0)"
-	    : [tmx] "+v"(tmx), [tmy] "+v"(tmy), [tmz] "+v"(tmz), [idx] "+v"(idx), [rx] "+v"(remx), [ry] "+v"(remy), [rz] "+v"(remz), [caddr] "+v"(caddr),
-	      [bit] "=&v"(bit), [word] "=&v"(word), [budget] "=&v"(budget), [cleft] "=&v"(cleft)
+	    : [tmx] "+v"(tmx), [tmy] "+v"(tmy), [tmz] "+v"(tmz), [idx] "+v"(idx), [prev] "+v"(prev), [rx] "+v"(remx), [ry] "+v"(remy), [rz] "+v"(remz),
+	      [caddr] "+v"(caddr), [bit] "=&v"(bit), [word] "=&v"(word), [budget] "=&v"(budget), [cleft] "=&v"(cleft)
 	    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [dix] "v"(dix), [diy] "v"(diy), [diz] "v"(diz), [pad] "s"(mask_pad_bit), [mbase] "s"(mask_base),
-	      [limit] "s"(idx_limit), [ncand1] "n"(RMD_WALK_CANDIDATES - 1), [look1] "n"(RMD_WALK_LOOKAHEAD - 1)
+	      [limit] "s"(idx_limit), [ncand1] "n"(RMD_WALK_CANDIDATES - 1), [look1] "n"(RMD_WALK_LOOKAHEAD - 1), [firstoff] "n"(sizeof(WalkScratch::start))
 	    : "vcc", "scc", "memory", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
 	n_cand = (caddr - cand_base) >> 8;
 	walking = bit == 0u;
@@ -320,7 +344,8 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	// the index by less than 2^31, so the wrapped 32-bit index is out of range exactly when the reference's usize one is.
 	const uint32_t idx_limit = (uint32_t)n_cells;
 	const RMD_GLOBAL CellEntry *entries = as_global(g.cell_entries);
-	const RMD_GLOBAL unsigned char *runs = as_global(reinterpret_cast<const unsigned char *>(g.tri_runs));
+	const RMD_GLOBAL uint32_t *ids = as_global(g.tri_ids);
+	const RMD_GLOBAL unsigned char *recs = as_global(reinterpret_cast<const unsigned char *>(g.tri_recs));
 #if RMD_DIAG
 	const bool stamp = (debug_flags & 16u) && dbg;
 	unsigned long long t_prev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -344,6 +369,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	[[maybe_unused]] bool start_outside = false;
 	int32_t dix = 0, diy = 0, diz = 0;
 	uint32_t idx = 0, remx = 1, remy = 1, remz = 1;
+	uint32_t prev = kNoCell; // the cell the ray stood on before `idx`: selects the triangle list of a candidate (device_types.hpp: cell_entries)
 	double tmx = 0.0, tmy = 0.0, tmz = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
 #if RMD_DIAG
 	const bool skip_walk = (debug_flags & 2u) != 0u, skip_tests = (debug_flags & 1u) != 0u; // timing ablations: wrong results, DIAG builds only
@@ -415,34 +441,41 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		// array (res.z <= res.y), so neither the shift nor the index test is needed as long as no lane of the wave started
 		// from a cell outside the grid (Q6).
 #if RMD_WALK_ASM_LOOP
-		if (mask_shift == 0u) { // one mask bit per cell (uniform): the assembly loop
+		if (mask_shift == 0u && !count_events) { // one mask bit per cell (uniform): the assembly loop (the event counters are in the C++ loop)
 			if (walking)
-				dda_collect_candidates_asm((uint32_t)(uintptr_t)lds_mask, mask_pad_bit, idx_limit, (uint32_t)(uintptr_t)&scr.first[lane], walking, n_cand, idx,
-				                           remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+				dda_collect_candidates_asm((uint32_t)(uintptr_t)lds_mask, mask_pad_bit, idx_limit, (uint32_t)(uintptr_t)&scr.start[lane], walking, n_cand, idx,
+				                           prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
 		}
 #else
 		const bool lean = lean_grid && __ballot(walking && start_outside) == 0ull;
-		if (lean) dda_collect_candidates<true>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+		if (lean) dda_collect_candidates<true>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
 #endif
-		else dda_collect_candidates<false>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+		else dda_collect_candidates<false>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, count_events ? dbg : nullptr);
 		RMD_STAMP(1)
 		if (__ballot(n_cand != 0u) == 0ull) {
 			if (__ballot(walking) == 0ull) break;
 			continue; // look-ahead budget used up without a candidate: keep stepping
 		}
 
-		// 2. the candidates' cell entries {first record, count}: all gathers of the round in flight together
+		// 2. the candidates' cell entries {first id, count}: all gathers of the round in flight together.  Which of a cell's lists: the one
+		//    without the triangles of the cell the ray came from, selected by the index step that led into the candidate (slot 0, the
+		//    full list, for a walk's first cell — and for a step that is none of the ray's three, which cannot happen)
 		uint32_t c_first[kWalkCand], c_count[kWalkCand];
 		{
 			// unconditional gathers (an unused slot reads cell 0) so that the kWalkCand loads overlap; masked afterwards
-			uint32_t ci[kWalkCand];
+			uint32_t ci[kWalkCand], pv[kWalkCand];
+			uint64_t ei[kWalkCand];
 #pragma unroll
-			for (uint32_t m = 0; m < kWalkCand; m++) ci[m] = scr.first[m * 64u + lane];
+			for (uint32_t m = 0; m < kWalkCand; m++) ci[m] = scr.first[m * 64u + lane], pv[m] = scr.start[m * 64u + lane];
 #pragma unroll
-			for (uint32_t m = 0; m < kWalkCand; m++) ci[m] = m < n_cand ? ci[m] : 0u;
+			for (uint32_t m = 0; m < kWalkCand; m++) {
+				const uint32_t step = ci[m] - pv[m];
+				const uint32_t slot = pv[m] == kNoCell ? 0u : step == (uint32_t)dix ? (dix > 0 ? 1u : 2u) : step == (uint32_t)diy ? (diy > 0 ? 3u : 4u) : step == (uint32_t)diz ? (diz > 0 ? 5u : 6u) : 0u;
+				ei[m] = m < n_cand ? (uint64_t)ci[m] * kEntrySlots + slot : 0ull;
+			}
 #pragma unroll
 			for (uint32_t m = 0; m < kWalkCand; m++) { // one 8-byte load per entry: {first, count}
-				const unsigned long long e = reinterpret_cast<const RMD_GLOBAL unsigned long long *>(entries)[ci[m]];
+				const unsigned long long e = reinterpret_cast<const RMD_GLOBAL unsigned long long *>(entries)[ei[m]];
 				c_first[m] = (uint32_t)e, c_count[m] = (uint32_t)(e >> 32);
 			}
 #pragma unroll
@@ -492,7 +525,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			// Owner search of one chunk: which (lane, candidate) pair test number base + lane belongs to, and its triangle record.
 			// It runs ONE CHUNK AHEAD of the tests (RMD_WALK_SEARCH_AHEAD): a chunk's record loads are issued first, then the
 			// rays are fetched and the next chunk is searched while the records are on their way.
-			auto search = [&](uint32_t base, uint32_t &own, uint32_t &rec_index) {
+			auto search = [&](uint32_t base, uint32_t &own, uint32_t &tri_id) {
 				const uint32_t w = base + lane;
 				scr.marker[lane] = 0u;
 				if (my_tests != 0u && my_begin < base + 64u && my_end > base) scr.marker[umax(my_begin, base) - base] = lane + 1u;
@@ -500,7 +533,8 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 				const uint32_t owner_lane = wave_scan_max(scr.marker[lane]) - 1u; // position 0 is always marked
-				own = 0, rec_index = 0;
+				own = 0;
+				uint32_t id_index = 0;
 				if (w < total) {
 					uint32_t slot = 0, slot_start = scr.start[owner_lane * kWalkCand];
 #pragma unroll
@@ -509,35 +543,27 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 						if (sm <= w) slot = m, slot_start = sm; // an empty slot shares its start with the next one: the last match is the non-empty pair
 					}
 					own = owner_lane | (slot << 8);
-					rec_index = scr.first[owner_lane * kWalkCand + slot] + (w - slot_start);
+					id_index = scr.first[owner_lane * kWalkCand + slot] + (w - slot_start);
 				}
+				tri_id = ids[id_index]; // (a lane without a test reads entry 0) — on its way while the current chunk is tested
 				__builtin_amdgcn_wave_barrier(); // every lane has read the markers before the next search rewrites them
 			};
-			uint32_t own = 0, rec_index = 0;
-			search(0u, own, rec_index);
+			uint32_t own = 0, tri_id = 0;
+			search(0u, own, tri_id);
 			for (uint32_t base = 0; base < total; base += 64u) {
 				const uint32_t w = base + lane;
-				// every lane loads a record (a lane without a test: record 0) and tests it — no zero-filled stand-in, no branch around the loads
-				const TriRecord r = load_record(runs + (size_t)rec_index * 80u);
+				// every lane loads a record (a lane without a test: some triangle's) and tests it — no zero-filled stand-in, no branch around the loads
+				const uint32_t tri = tri_id;
+				const TriRecord r = load_record(recs + (size_t)tri * kTriRecStride);
 				// the owner lane's ray, straight from its registers (every lane takes part in the permute)
 				const int src = (int)((own & 63u) << 2);
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				const uint32_t own_now = own;
-				if (base + 64u < total) search(base + 64u, own, rec_index);
-				uint32_t prefetched = 0;
-#if RMD_WALK_PREFETCH
-				// touch the next chunk's records (one word each: neighbouring tests read neighbouring records, so every line of a run is
-				// touched) so that its loads find them in the nearer caches.  Unconditional — lanes without a next test touch a record
-				// they already have — so that the wait for this chunk's records can leave exactly this one load outstanding; the word
-				// is only "used" after this chunk's tests.
-				prefetched = *reinterpret_cast<const RMD_GLOBAL uint32_t *>(runs + (size_t)rec_index * 80u);
-#endif
+				if (base + 64u < total) search(base + 64u, own, tri_id);
 				double t = 0.0;
-				const uint32_t tri = r.tri;
 				const bool h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t) && w < total;
 				RMD_STAMP(5)
-				asm volatile("" ::"v"(prefetched));
 				unsigned long long hits = __ballot(h);
 				while (hits) {
 					const int l = (int)__builtin_ctzll(hits);

@@ -231,7 +231,7 @@ def block_uniforms(seed, pixel, sample, block):
 def counters():
     out = np.zeros(12, dtype=np.uint64)
     load().orc_counters_get(ptr(out))
-    names = ["samples", "segments", "cells", "tri_tests", "mesh_hits", "bounces", "draws", "walks", "occupied_cells", "zero_weight_diffuse", "zero_weight_specular"]
+    names = ["samples", "segments", "cells", "tri_tests", "mesh_hits", "bounces", "draws", "walks", "occupied_cells", "zero_weight_diffuse", "zero_weight_specular", "retests"]
     return dict(zip(names, (int(v) for v in out)))
 
 
