@@ -48,6 +48,8 @@ def parse():
                          "rmd_comm_* / rmd_reduce_framebuffer (RCCL, one rank per GPU); all bit-identical to the 1-GPU frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="only the timed workload and the roofline leg in its default mode (tools/profile_round.sh: the rocprofv3 "
+                                                         "kernel-trace then averages each kernel over one workload, as the bench line does)")
     return ap.parse_args()
 
 
@@ -144,6 +146,11 @@ def valu_block(name, avg_ms):
     # the fraction of the vector ALUs' issue slots this launch fills, and the fraction that does useful work (active lanes)
     v["valu_issue_frac"] = round(VALU_ISSUE_NS / v["simd_ns_per_valu_instr"], 4)
     v["useful_frac"] = round(v["valu_issue_frac"] * v["lane_utilisation"], 4)
+    if "valu_stream_ms" in v:
+        # the launch's instruction stream priced class by class (f64 arithmetic 2.05 ns, rcp / rsq 6.7 ns, the rest 0.95 .. 1.28 ns per wave instruction
+        # per SIMD: tools/microbench/valu_rate.hip) against this run's duration: how busy the vector ALUs are — valu_issue_frac prices every
+        # instruction at the 1.667 ns of a 4-cycle issue and so underrates a stream of f64 operations
+        v["valu_busy_frac"] = {"low": round(v["valu_stream_ms"]["low"] / avg_ms, 4), "high": round(v["valu_stream_ms"]["high"] / avg_ms, 4)}
     return v
 
 
@@ -155,8 +162,10 @@ def bound_by_counters(rl):
         return None, None
     mem = rl.get("measured_frac")
     bound = "valu" if mem is None or v["valu_issue_frac"] >= mem else "hbm"
-    text = "%s: %.2f of the VALU issue slots busy at %.1f %% lanes (useful %.2f), measured L2<->fabric traffic %s of the HBM peak%s" % (
+    busy = v.get("valu_busy_frac")
+    text = "%s: %.2f of the VALU issue slots busy at %.1f %% lanes (useful %.2f)%s, measured L2<->fabric traffic %s of the HBM peak%s" % (
         "VALU issue" if bound == "valu" else "HBM", v["valu_issue_frac"], 100.0 * v["lane_utilisation"], v["useful_frac"],
+        "" if not busy else "; the instruction stream at its classes' measured issue costs keeps the vector ALUs busy %.2f - %.2f of the time" % (busy["low"], busy["high"]),
         "n/a" if mem is None else "%.3f" % mem, " (PMC figures are STALE: collected at other sources)" if v.get("stale") else "")
     return bound, text
 
@@ -346,7 +355,7 @@ def main():
 
     # for the record, beside `value`: the same frame with every path traced to its end as the reference does (RMD_RENDER_TRACE_BLACK_PATHS) —
     # the same checksum, the reference's full number of path segments
-    if world == 1 and not args.no_roofline_leg:
+    if world == 1 and not args.no_roofline_leg and not args.lean:
         full = run_workload(name, spp, 1, 1, reduce=False, mode="trace")
         out["tracing_black_paths"] = {
             "value": round(full["samples_per_step"] / full["elapsed"] / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(full["elapsed"] * 1e3, 3),
@@ -432,26 +441,27 @@ def main():
                    "sum_kernel over the same launches; valu / traffic: committed rocprofv3 --pmc passes (separate SQ / FETCH_SIZE / WRITE_SIZE passes), "
                    "\"stale\": true when the sources have changed since",
         })
-        end = mesh_leg("end", max(1, args.roofline_steps - 1), "C3", "C3_end")
-        end["note"] = ("rmd_settings.flags = RMD_RENDER_END_BLACK_PATHS (opt-in on mesh scenes): zero-throughput paths ended; every sample that is finite in the "
-                       "reference keeps its value bit for bit, a sample the reference makes NaN behind a zero weight comes out (0, 0, 0)")
-        rl["ending_black_paths"] = end
         out["roofline"] = rl
-        # the other mesh configurations of BASELINE.json on this GPU, short launches (throughput does not depend on the sample count): both modes
-        cfg = {}
-        for cname, cspp in (("C4", 20), ("C5", 50)):
-            for mode in ("default", "end"):
-                r = run_workload(cname, cspp, 1, 1, reduce=False, mode=mode)
-                ms = sum(r["kernel_ms"]) / len(r["kernel_ms"])
-                cfg.setdefault(cname, {"workload": "%s, %dx%d, %d bounces%s; %d-spp launch of the config's %d" % (
-                    scenes.CONFIGS[cname][0], r["W"], r["H"], r["st"].bounce_limit, ", thin lens (RMD_RENDER_DOF)" if r["st"].use_dof else "", cspp, scenes.CONFIGS[cname][3])})
-                cfg[cname]["reference_identical" if mode == "default" else "ending_black_paths"] = {
-                    "kernel_ms": round(ms, 3), "msamples_per_s": round(r["samples_per_step"] / (ms * 1e-3) / 1e6, 2)}
-        cfg["C3"] = {"workload": rl["workload"], "reference_identical": {"kernel_ms": rl["avg_ms"], "msamples_per_s": rl["msamples_per_s"]},
-                     "ending_black_paths": {"kernel_ms": end["avg_ms"], "msamples_per_s": end["msamples_per_s"]}}
-        cfg["C2"] = {"workload": out["config"]["workload"], "reference_identical": {"kernel_ms": out["kernel"]["avg_ms"], "msamples_per_s": round(value, 2)},
-                     "tracing_black_paths": {"kernel_ms": out["tracing_black_paths"]["ms_per_step"], "msamples_per_s": out["tracing_black_paths"]["value"]}}
-        out["configs"] = cfg
+        if not args.lean:
+            end = mesh_leg("end", max(1, args.roofline_steps - 1), "C3", "C3_end")
+            end["note"] = ("rmd_settings.flags = RMD_RENDER_END_BLACK_PATHS (opt-in on mesh scenes): zero-throughput paths ended; every sample that is finite in the "
+                           "reference keeps its value bit for bit, a sample the reference makes NaN behind a zero weight comes out (0, 0, 0)")
+            rl["ending_black_paths"] = end
+            # the other mesh configurations of BASELINE.json on this GPU, short launches (throughput does not depend on the sample count): both modes
+            cfg = {}
+            for cname, cspp in (("C4", 20), ("C5", 50)):
+                for mode in ("default", "end"):
+                    r = run_workload(cname, cspp, 1, 1, reduce=False, mode=mode)
+                    ms = sum(r["kernel_ms"]) / len(r["kernel_ms"])
+                    cfg.setdefault(cname, {"workload": "%s, %dx%d, %d bounces%s; %d-spp launch of the config's %d" % (
+                        scenes.CONFIGS[cname][0], r["W"], r["H"], r["st"].bounce_limit, ", thin lens (RMD_RENDER_DOF)" if r["st"].use_dof else "", cspp, scenes.CONFIGS[cname][3])})
+                    cfg[cname]["reference_identical" if mode == "default" else "ending_black_paths"] = {
+                        "kernel_ms": round(ms, 3), "msamples_per_s": round(r["samples_per_step"] / (ms * 1e-3) / 1e6, 2)}
+            cfg["C3"] = {"workload": rl["workload"], "reference_identical": {"kernel_ms": rl["avg_ms"], "msamples_per_s": rl["msamples_per_s"]},
+                         "ending_black_paths": {"kernel_ms": end["avg_ms"], "msamples_per_s": end["msamples_per_s"]}}
+            cfg["C2"] = {"workload": out["config"]["workload"], "reference_identical": {"kernel_ms": out["kernel"]["avg_ms"], "msamples_per_s": round(value, 2)},
+                         "tracing_black_paths": {"kernel_ms": out["tracing_black_paths"]["ms_per_step"], "msamples_per_s": out["tracing_black_paths"]["value"]}}
+            out["configs"] = cfg
     elif rank == 0:
         out["roofline"] = out.get("roofline_%s" % name.lower())
 

@@ -41,7 +41,7 @@ pub struct rmd_grid_desc {
 #[repr(C)]
 pub struct rmd_camera { pub backbuffer_width: u32, pub backbuffer_height: u32, pub fov_vert: f64, pub position: [f64; 3], pub focal_length: f64, pub aperture_radius: f64 }
 #[repr(C)]
-pub struct rmd_settings { pub bounce_limit: u32, pub sample_begin: u32, pub sample_count: u32, pub flags: u32 /* 0, RMD_RENDER_DOF = 1, RMD_RENDER_TRACE_BLACK_PATHS = 2 */, pub seed: u64 }
+pub struct rmd_settings { pub bounce_limit: u32, pub sample_begin: u32, pub sample_count: u32, pub flags: u32 /* 0 = the reference-identical mode; RMD_RENDER_DOF = 1, RMD_RENDER_TRACE_BLACK_PATHS = 2, RMD_RENDER_END_BLACK_PATHS = 4 */, pub seed: u64 }
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct rmd_tile_rect { pub left: u32, pub top: u32, pub width: u32, pub height: u32 }
@@ -177,8 +177,11 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
                 let begin = batch[0].sample_count;
                 let n = pass.min(settings.sample_count - begin);
                 let rects: Vec<rmd_tile_rect> = batch.iter().map(|t| rmd_tile_rect { left: t.left as u32, top: t.top as u32, width: t.width as u32, height: t.height as u32 }).collect();
-                // flags: 0 — the reference's loop calls the pinhole generate_primary_ray whatever cam.aperture_radius holds (:199);
-                // RMD_RENDER_DOF (1) would opt into generate_primary_ray_with_dof, which the reference defines but never calls
+                // flags: 0 — the drop-in mode.  The reference's loop calls the pinhole generate_primary_ray whatever cam.aperture_radius holds (:199);
+                // RMD_RENDER_DOF (1) would opt into generate_primary_ray_with_dof, which the reference defines but never calls.  With 0 every sample
+                // is the reference's, NaN for NaN: paths whose throughput is exactly zero are ended only in scenes without a mesh, where that is
+                // provably exact; RMD_RENDER_END_BLACK_PATHS (4) would end them on mesh scenes too (1.6x faster; a sample the reference makes
+                // 0 x NaN = NaN then comes out 0 — raymond_hip.h)
                 let st = rmd_settings { bounce_limit: settings.bounce_limit as u32, sample_begin: begin as u32, sample_count: n as u32, flags: 0, seed };
                 // the tiles' running sums go up, the kernel adds samples begin..begin+n to them one by one (`+=` of :203, in sample
                 // order: progressive passes give the same bits as one pass), and the sums come back

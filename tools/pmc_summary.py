@@ -64,6 +64,20 @@ if json_out:
                 "valu_active_per_wave": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
                 "wave_instr_valu_per_launch": c["SQ_INSTS_VALU"],
             }
+            if "SQ_INSTS_VALU_FMA_F64" in c and "SQ_INSTS_VALU_INT32" in c:
+                # the instruction mix, per sample, and the time the vector ALUs need for this stream: ns per wave instruction per SIMD measured with
+                # tools/microbench/valu_rate.hip (profiles/r03_valu_rate.txt): f64 add / mul / fma 2.05, v_rcp / v_rsq_f64 6.7, everything else
+                # (32-bit integer and bit operations, moves, selects; f64 compares priced as those) 0.95 .. 1.28
+                f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
+                trans = c["SQ_INSTS_VALU_TRANS_F64"]
+                other = c["SQ_INSTS_VALU"] - f64 - trans
+                valu[wl]["mix_per_sample"] = {"f64_add": c["SQ_INSTS_VALU_ADD_F64"] / n, "f64_mul": c["SQ_INSTS_VALU_MUL_F64"] / n, "f64_fma": c["SQ_INSTS_VALU_FMA_F64"] / n,
+                                              "f64_rcp_rsq": trans / n, "int32": c["SQ_INSTS_VALU_INT32"] / n, "int64": c["SQ_INSTS_VALU_INT64"] / n, "cvt": c["SQ_INSTS_VALU_CVT"] / n,
+                                              "moves_selects_compares": (other - c["SQ_INSTS_VALU_INT32"] - c["SQ_INSTS_VALU_INT64"] - c["SQ_INSTS_VALU_CVT"]) / n,
+                                              "salu": c.get("SQ_INSTS_SALU", 0.0) / n, "branch": c.get("SQ_INSTS_BRANCH", 0.0) / n, "lds": c.get("SQ_INSTS_LDS", 0.0) / n,
+                                              "vmem_read": c.get("SQ_INSTS_VMEM_RD", 0.0) / n, "smem": c.get("SQ_INSTS_SMEM", 0.0) / n}
+                valu[wl]["valu_stream_ms"] = {"low": (f64 * 2.05 + trans * 6.7 + other * 0.95) / N_SIMD * 1e-6, "high": (f64 * 2.05 + trans * 6.7 + other * 1.28) / N_SIMD * 1e-6,
+                                              "how": "sum over instruction classes of count x measured issue cost / 1,024 SIMDs; low / high = the other-class cost of 0.95 / 1.28 ns"}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             fetch = c["FETCH_SIZE"] + c.get("FETCH_SIZE[sum_kernel]", 0.0)
             write = c["WRITE_SIZE"] + c.get("WRITE_SIZE[sum_kernel]", 0.0)
