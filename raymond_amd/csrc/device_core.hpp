@@ -122,6 +122,16 @@ RMD_DEV V3 normalize_for_weight(V3 a) {
 	return a * y;
 }
 
+// A binary64 constant made on the spot in a scalar register pair.  Written as a literal the compiler materialises such a constant in a vector
+// register pair, hoists that out of the render loop and — at the grid kernel's register limit — spills it: the trip then waits on a scratch
+// load for the value of a constant (three of them, five reloads per trip, in round 3's grid kernel).  volatile: stays where it is used.
+RMD_DEV double scalar_const(double c) {
+	const unsigned long long b = __builtin_bit_cast(unsigned long long, c);
+	uint32_t lo, hi;
+	asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"((uint32_t)b), "n"((uint32_t)(b >> 32)));
+	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 constexpr double kPi = 3.14159265358979323846; // core/src/math.rs:19
 constexpr double kFMax = 1.7976931348623157e308; // core/src/math.rs:20
 
@@ -283,7 +293,8 @@ RMD_DEV V3 triangle_normal_with(P pos9, P nrm9, double side_ab, double side_ac, 
 	double abp = heron_area_of_sides(side_ab, d0, d1); // heron_area(p0, p1, position)
 	double bcp = heron_area_of_sides(side_ac, d0, d2); // heron_area(p0, p2, position)
 	double ba, bb;
-	if (inv_abc == inv_abc && abp < kFMax && bcp < kFMax) ba = div_by(abp, abc, inv_abc), bb = div_by(bcp, abc, inv_abc);
+	const double fmax_ = scalar_const(kFMax);
+	if (inv_abc == inv_abc && abp < fmax_ && bcp < fmax_) ba = div_by(abp, abc, inv_abc), bb = div_by(bcp, abc, inv_abc);
 	else ba = abp / abc, bb = bcp / abc; // degenerate or all-ones area, or a non-finite numerator: the plain divisions
 	double bc = 1.0 - (ba + bb);
 	V3 n = (ld3(nrm9 + 6) * ba) + (ld3(nrm9 + 3) * bb) + (ld3(nrm9) * bc);
@@ -564,7 +575,7 @@ RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const 
 		}
 		const V3 wgt = vec * (N * fast_rcp(Dn));
 		T = hadamard(T, wgt);
-		ro = in.frag + normal * (diffuse ? 0.00001 : 0.0001); // :269 / :300
+		ro = in.frag + normal * (diffuse ? scalar_const(0.00001) : scalar_const(0.0001)); // :269 / :300
 		rd = sw;
 	}
 }

@@ -157,8 +157,12 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 	}
 	const bool writes = alive;
 
+	// direct mode of the grid kernel (launches of a few samples per pixel: progressive passes): the pixel's running sum stays in memory and
+	// every finished sample is added to it there — the same additions in the same order as a sum kept in registers, which at this kernel's
+	// register limit was six spilled registers (a lane owns its pixel for the whole launch: no other lane touches it)
+	constexpr bool acc_in_memory = GRID && MODE == kModeTiles;
 	V3 acc = mk(0.0, 0.0, 0.0);
-	if (!LIST && alive && !to_buffer) acc = ld3(out + out_index);
+	if (!LIST && alive && !to_buffer && !acc_in_memory) acc = ld3(out + out_index);
 	if (P.bounce_limit == 0u) { // trace(.., 1) with depth 1 > bounce_limit returns 0 unintersected (:235-237): every sample is (0, 0, 0)
 		if (LIST && writes) out[out_index + 0] = 0.0, out[out_index + 1] = 0.0, out[out_index + 2] = 0.0;
 		return; // tile launches with bounce_limit 0 are not made at all (api.cpp): the frame is unchanged
@@ -313,7 +317,12 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 				// sample through with three 8-byte agent-scope stores: 96 bytes at the memory side per 24-byte sample)
 				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
 			} else {
-				acc = acc + L; // src/trace.rs:203
+				if constexpr (acc_in_memory) {
+					RMD_GLOBAL double *px = (RMD_GLOBAL double *)out + ((size_t)(tile.x0 + (lane & 7u)) + (size_t)(tile.y0 + (lane >> 3)) * Pt.W) * 3;
+					px[0] += L.x, px[1] += L.y, px[2] += L.z; // src/trace.rs:203
+				} else {
+					acc = acc + L; // src/trace.rs:203
+				}
 				s++;
 			}
 			has_ray = false;
@@ -355,6 +364,8 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		if constexpr (to_buffer) {
 			x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 			s = Pt.sample_begin + pool_first + (item >> 6);
+		} else if constexpr (acc_in_memory) {
+			x = tile.x0 + (lane & 7u), y = tile.y0 + (lane >> 3); // recomputed per trip instead of carried (registers)
 		}
 		Rng rng;
 		rng.pixel = y * Pt.W + x, rng.sample = s, rng.block = rng_block, rng.lobe_bits = lobe_bits;
@@ -476,7 +487,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			}
 		}
 	}
-	if (writes && !to_buffer) {
+	if (writes && !to_buffer && !acc_in_memory) {
 		out[out_index + 0] = acc.x;
 		out[out_index + 1] = acc.y;
 		out[out_index + 2] = acc.z;

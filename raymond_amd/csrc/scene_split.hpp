@@ -15,7 +15,7 @@ namespace rmd {
 RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return t < t_best || (t == t_best && obj < obj_best); }
 RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, bool want, V3 ro, V3 rd,
                               double &closest, int &best) {
-	closest = kFMax, best = -1;
+	closest = scalar_const(kFMax), best = -1;
 	bool enters = false;
 	for (uint32_t i = 0; i < n_objects; i++) {
 		const DevObject &o = objs[i];
