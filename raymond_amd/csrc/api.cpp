@@ -365,7 +365,9 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		for (uint64_t c = 0; c < g.n_cells; c++)
 			if (entries[c * rmd::kEntrySlots].count) last_nonempty = c, any_nonempty = true;
 		// occupancy bitmask for LDS: bit i covers cells [i << shift, (i+1) << shift); only up to the last non-empty cell
-		const uint64_t covered = any_nonempty ? last_nonempty + 1 : 0;
+		// the mask covers every cell of the array when that fits the budget (the stepping loop's lean form then needs no clamp of the index),
+		// else the cells up to the last non-empty one (indices past it read the all-zero word that ends every mask)
+		uint64_t covered = any_nonempty ? last_nonempty + 1 : 0;
 		size_t budget_bytes = rmd::kMaskBudgetBytes;
 		if (ctx->tunable[RMD_TUNE_MASK_BUDGET] > 0) budget_bytes = (size_t)ctx->tunable[RMD_TUNE_MASK_BUDGET]; // forces coarser masks
 		if (budget_bytes < 64) budget_bytes = 64;
@@ -375,6 +377,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 			rmd_scene_destroy(sc);
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: too many grids for the LDS occupancy-mask budget");
 		}
+		if ((g.n_cells + 31) / 32 + 1 <= budget_words) covered = g.n_cells;
 		uint32_t shift = 0;
 		while (shift < 63 && ((covered >> shift) + 31) / 32 + 1 > budget_words) shift++;
 		const uint64_t bits = covered ? ((covered - 1) >> shift) + 1 : 0;
