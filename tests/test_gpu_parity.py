@@ -499,6 +499,27 @@ def test_black_path_modes_change_no_finite_sample(gpu_ctx, oracle, small_mesh_sc
     assert rel_close(frames["default"], ref, 1e-9).all(axis=2).mean() >= 0.995
 
 
+def test_contradictory_or_unknown_flags_are_refused(gpu_ctx):
+    """RMD_RENDER_TRACE_BLACK_PATHS and RMD_RENDER_END_BLACK_PATHS exclude each other; bits the header does not define are refused too."""
+    import ctypes as C
+
+    from raymond_amd import lib
+    from raymond_amd.scene import tile_array
+
+    sc = scenes.reflective_spheres()
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, 32, 32)
+    cam = scenes.camera(32, 32).pod()
+    tiles = tile_array([(0, 0, 32, 32)])
+    for flags in (abi.RMD_RENDER_TRACE_BLACK_PATHS | abi.RMD_RENDER_END_BLACK_PATHS, 8, 1 << 31):
+        st = Settings(scenes.camera(32, 32), sample_count=1).pod()
+        st.flags = flags
+        status = gpu_ctx.L.rmd_render_tiles(gpu_ctx.handle, ds.handle, C.byref(cam), C.byref(st), tiles, 1, fb.ptr)
+        assert status == abi.RMD_ERR_INVALID_ARGUMENT, (flags, status)
+    assert (fb.download() == 0).all()  # nothing was rendered
+    fb.close(), ds.close()
+
+
 def nan_normal_scene(n=6, every=2):
     """cli_old's room with a small mesh in the dragon's place, every second triangle of which has vertex normals (0, 0, 0): the interpolated
     normal of a hit on it is normalize(0) = 0 * (1 / 0) = NaN (triangle.rs:60-67, cgmath normalize) — the non-finite vertex that a real mesh
