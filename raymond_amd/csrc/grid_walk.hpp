@@ -499,25 +499,17 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		}
 		RMD_STAMP(2)
 
-		// 3. triangle tests, distributed over the whole wave.  The (lane, candidate) pairs of this round own `count`
-		//    tests each; an exclusive prefix sum over the counts numbers all tests of the round 0..T-1 in
-		//    (lane, candidate, triangle) order and the wave takes them 64 at a time: lane l of a chunk finds its pair by
-		//    binary search in the scanned counts (LDS), fetches that pair's ray from its owner lane's registers
-		//    (ds_bpermute) and the triangle record from the cell's contiguous run (neighbouring lanes read neighbouring
-		//    80-byte records: coalesced).  Hits are rare; they are applied by a scalar loop over the hit ballot in ascending
-		//    lane order = ascending (lane, candidate, triangle) order with a strict '<': within a candidate cell that is
-		//    the reference's sequential scan (acc_grid.rs:135-149: closest starts at 5712515.0, first wins ties), and
-		//    across candidates the earliest cell with an accepted hit wins (:151-153).
 		// 3. triangle tests, distributed over the whole wave.  Lane l's candidates own c_count[0..] tests each; an exclusive
 		//    prefix sum over the lanes numbers all tests of the round 0..T-1 in (lane, candidate, triangle) order and the wave
 		//    takes them 64 at a time.  For a chunk, every lane whose tests overlap it drops lane+1 at the position where its
 		//    tests begin inside the chunk (LDS), a max-scan carries that to the following positions, and each test then finds
 		//    its candidate slot by comparing against the owner's pair starts (one 16-byte LDS read).  It fetches that pair's
-		//    ray from its owner lane's registers (ds_bpermute) and the triangle record from the cell's contiguous run
-		//    (neighbouring lanes read neighbouring 80-byte records: coalesced).  Hits are rare; they are applied by a scalar
-		//    loop over the hit ballot in ascending lane order = ascending (lane, candidate, triangle) order with a strict '<':
-		//    within a candidate cell that is the reference's sequential scan (acc_grid.rs:135-149: closest starts at
-		//    5712515.0, first wins ties), and across candidates the earliest cell with an accepted hit wins (:151-153).
+		//    ray from its owner lane's registers (ds_bpermute), its triangle's index from the candidate's list (neighbouring
+		//    tests read neighbouring entries of tri_ids) and the triangle's record by that index.  Hits are rare; they are applied
+		//    by a scalar loop over the hit ballot in ascending lane order = ascending (lane, candidate, triangle) order with a
+		//    strict '<': within a candidate cell that is the reference's sequential scan (acc_grid.rs:135-149: closest starts at
+		//    5712515.0, first wins ties) over the triangles that can still hit (the list leaves out those the previous cell
+		//    tested: they missed), and across candidates the earliest cell with an accepted hit wins (:151-153).
 		uint32_t my_tests = 0;
 #pragma unroll
 		for (uint32_t m = 0; m < kWalkCand; m++) my_tests += c_count[m];
