@@ -128,7 +128,7 @@ rmd_status check_render_args(rmd_context *ctx, const rmd_scene *scene, const rmd
 	if (st->flags & ~(RMD_RENDER_DOF | RMD_RENDER_TRACE_BLACK_PATHS | RMD_RENDER_END_BLACK_PATHS)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: unknown bits in rmd_settings.flags");
 	if ((st->flags & RMD_RENDER_TRACE_BLACK_PATHS) && (st->flags & RMD_RENDER_END_BLACK_PATHS))
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: RMD_RENDER_TRACE_BLACK_PATHS and RMD_RENDER_END_BLACK_PATHS exclude each other");
-	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, 1) > rmd::kLdsBudgetBytes)
+	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, 1) + (scene->n_grids == 0u ? rmd::kSortPoolBytes : 0u) > rmd::kLdsBudgetBytes)
 		return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: object table + grid masks exceed the 160 KiB LDS of a CU");
 	return RMD_OK;
 }

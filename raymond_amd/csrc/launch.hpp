@@ -49,6 +49,18 @@ constexpr double kMaxRoughness = 512.0;
 constexpr uint32_t kGridWavesPerWg = RMD_GRID_WAVES;
 // waves of a persistent workgroup (one per CU: all 16 wave slots that 128 registers per lane leave)
 constexpr uint32_t kPersistWavesPerWg = 16;
+// the spheres kernel's split launches (render_kernel.hpp: render_wave_sorted): path slots of a wave's pool and waves of a persistent workgroup —
+// 16 pools of 112 slots (86 bytes each) and the object table fit the CU's 160 KB
+#ifndef RMD_SORT_SLOTS
+#define RMD_SORT_SLOTS 112
+#endif
+#ifndef RMD_SORT_WAVES
+#define RMD_SORT_WAVES 16 // waves of one persistent workgroup
+#endif
+#ifndef RMD_SORT_WGS_PER_CU
+#define RMD_SORT_WGS_PER_CU 1 // persistent workgroups per CU (a workgroup holds at most 16 waves)
+#endif
+constexpr size_t kSortPoolBytes = 86u * RMD_SORT_SLOTS; // per-wave LDS (sizeof(SortPool))
 size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg);
 uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total);
 // n_cus > 0 and P.work_counter set: grid scenes run as persistent workgroups (render_kernel.hpp)

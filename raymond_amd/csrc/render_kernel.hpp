@@ -100,6 +100,41 @@ enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
 #ifndef RMD_TRIP_RELOAD
 #define RMD_TRIP_RELOAD 1
 #endif
+// The end of a (wave tile, sample range) work item of the spheres kernel: the wave that finishes a wave tile's LAST sample range adds the tile's
+// samples to the pixels, strictly in sample order (src/trace.rs:203: the reference's sequential sum, bit for bit) — inside the render kernel, where
+// the reads (bandwidth) overlap the other waves' arithmetic; as a kernel of its own the sum cost 5.5 ms per 1080p / 500 spp frame.  Release: an
+// agent-scope fence writes this wave's sample stores back before its count; acquire: the last wave invalidates its caches before it reads.
+RMD_DEV void finish_sample_range(const RenderParams &P, const WaveTile &tile, uint32_t wt, uint32_t lane, double *__restrict__ out) {
+	if (P.tile_done == nullptr || wt >= P.n_work) return;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's samples leave the XCD's L2 before its count is seen
+	uint32_t before = 0;
+	if (lane == 0u) before = __hip_atomic_fetch_add(P.tile_done + wt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+	if (before + 1u != P.split_k) return;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	const uint32_t lx = lane & 7u, ly = lane >> 3;
+	if (lx < tile.w && ly < tile.h) {
+		const size_t pix = ((size_t)(tile.x0 + lx) + (size_t)(tile.y0 + ly) * P.W) * 3;
+		V3 sum = ld3(out + pix);
+		const RMD_GLOBAL double *src = (const RMD_GLOBAL double *)P.sample_buf + ((size_t)wt * P.sample_count * 64u + lane) * kSampleStride;
+		// 16 samples' loads in flight at a time (the additions stay in sample order)
+		uint32_t k = 0;
+		for (; k + 16u <= P.sample_count; k += 16u) {
+			V3 v[16];
+#pragma unroll
+			for (uint32_t j = 0; j < 16u; j++) v[j] = ld3(src + (size_t)j * 64u * kSampleStride);
+#pragma unroll
+			for (uint32_t j = 0; j < 16u; j++) sum = sum + v[j];
+			src += 16u * 64u * kSampleStride;
+		}
+		for (; k < P.sample_count; k++) {
+			sum = sum + ld3(src);
+			src += 64u * kSampleStride;
+		}
+		out[pix + 0] = sum.x, out[pix + 1] = sum.y, out[pix + 2] = sum.z;
+	}
+}
+
 // One wave's share of a launch: list mode — the 64 entries from `first`; tile modes — work item `first` = (wave tile, sample
 // sub-range).  Called by all 64 lanes of a wave in uniform control flow; lobjs / lds_masks / wave_lds are the workgroup's staged
 // object table and occupancy masks and this wave's scratch in LDS.
@@ -451,42 +486,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 	}
 #endif
 #undef RMD_TSTAMP
-	if constexpr (to_buffer && !GRID) { // (mesh scenes keep sum_kernel: api.cpp)
-		// The wave that finishes a wave tile's last sample range adds the tile's samples to the pixels, strictly in sample order
-		// (src/trace.rs:203: the reference's sequential sum, bit for bit) — inside this kernel, where the reads (bandwidth) overlap the
-		// other waves' arithmetic; as a kernel of its own the sum cost 5.5 ms per 1080p / 500 spp frame.  Release: an agent-scope fence
-		// writes this wave's sample stores back before its count; acquire: the last wave invalidates its caches before it reads.
-		if (P.tile_done != nullptr && wt < P.n_work) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's samples leave the XCD's L2 before its count is seen
-			uint32_t before = 0;
-			if (lane == 0u) before = __hip_atomic_fetch_add(P.tile_done + wt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-			if (before + 1u == P.split_k) {
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-				const uint32_t lx = lane & 7u, ly = lane >> 3;
-				if (lx < tile.w && ly < tile.h) {
-					const size_t pix = ((size_t)(tile.x0 + lx) + (size_t)(tile.y0 + ly) * P.W) * 3;
-					V3 sum = ld3(out + pix);
-					const RMD_GLOBAL double *src = (const RMD_GLOBAL double *)P.sample_buf + ((size_t)wt * P.sample_count * 64u + lane) * kSampleStride;
-					// 16 samples' loads in flight at a time (the additions stay in sample order)
-					uint32_t k = 0;
-					for (; k + 16u <= P.sample_count; k += 16u) {
-						V3 v[16];
-#pragma unroll
-						for (uint32_t j = 0; j < 16u; j++) v[j] = ld3(src + (size_t)j * 64u * kSampleStride);
-#pragma unroll
-						for (uint32_t j = 0; j < 16u; j++) sum = sum + v[j];
-						src += 16u * 64u * kSampleStride;
-					}
-					for (; k < P.sample_count; k++) {
-						sum = sum + ld3(src);
-						src += 64u * kSampleStride;
-					}
-					out[pix + 0] = sum.x, out[pix + 1] = sum.y, out[pix + 2] = sum.z;
-				}
-			}
-		}
-	}
+	if constexpr (to_buffer && !GRID) finish_sample_range(P, tile, wt, lane, out); // (mesh scenes keep sum_kernel: api.cpp)
 	if (writes && !to_buffer && !acc_in_memory) {
 		out[out_index + 0] = acc.x;
 		out[out_index + 1] = acc.y;
@@ -494,12 +494,195 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Split launches of scenes WITHOUT grids (the spheres kernel): trips sorted by role.
+//
+// In render_wave() a lane keeps its path and every trip runs ONE merged instruction stream for the two things a lane may need — the
+// shading of the hit it carries, or the primary ray of its next sample.  With zero-throughput paths ended a sample is 2.13 path segments,
+// so 47 % of a trip's lanes start a sample and sit out the shading stream (331 of the trip's ~940 vector instructions) while the other
+// 53 % sit out ray generation: 68 % lane utilisation, measured.  Here the wave owns a POOL of kSortSlots path slots in LDS and a trip is
+// one of two kinds, each with (up to) 64 lanes that all need the same thing:
+//   GI  64 empty slots take the work item's next 64 (pixel, sample) pairs: primary ray (src/trace.rs:322-333, thin lens :335-360),
+//       intersection, classification;
+//   SI  64 slots that hold a hit to shade: shading (:256-319) -> bounce ray, intersection, classification.
+// Classification (:242-252 and the rules of DESIGN.md section 3) ends a path — its sample goes to the per-sample buffer, its slot to the
+// empty list — or parks the hit in its slot (hit point, normal, throughput, RNG state: 9 doubles + 3 words) on the hit list.  A path's
+// arithmetic is the same functions in the same order as in render_wave(): every sample has the same bits; which lane and which trip
+// compute it changes nothing (the RNG is keyed by pixel and sample, the samples are added in order afterwards).  With
+// n_empty + n_hit = kSortSlots = 128 one of the two lists always holds 64 entries while the item has pairs left; when it runs out the
+// remaining hits are shaded in ever smaller trips (~3 of an item's ~120).
+#ifndef RMD_SORTED_TRIPS
+#define RMD_SORTED_TRIPS 1
+#endif
+constexpr uint32_t kSortSlots = RMD_SORT_SLOTS; // (launch.hpp)
+struct alignas(16) SortPool {
+	double frag[3][kSortSlots], normal[3][kSortSlots], T[3][kSortSlots]; // the parked hit: point, surface normal; the path's throughput
+	uint32_t state[kSortSlots];     // object (16 bits) | next RNG block (16)
+	uint32_t lobe_bits[kSortSlots]; // the 22 spare bits of the path's last block | depth << 24
+	uint32_t item[kSortSlots]; // the path's (pixel, sample) pair: its number in the work item's pool
+	uint8_t empty_list[kSortSlots], hit_list[kSortSlots];
+};
+static_assert(kSortSlots >= 64u && kSortSlots <= 256u && kSortSlots % 8u == 0u, "slot numbers are bytes");
+static_assert(sizeof(SortPool) == kSortPoolBytes, "launch.hpp: kSortPoolBytes");
+// waves of a persistent workgroup of this kernel: 12 pools + the object table fit the CU's 160 KB (3 waves per SIMD; the kernel is
+// vector-ALU bound and times the same at 2 .. 5)
+constexpr uint32_t kSortedWavesPerWg = RMD_SORT_WAVES;
+
+RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_params, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids,
+                                const void *__restrict__ work, double *__restrict__ out, const DevObject *lobjs, unsigned char *wave_lds, uint32_t work_item) {
+	const uint32_t lane = threadIdx.x & 63u;
+	SortPool &pool = *reinterpret_cast<SortPool *>(wave_lds);
+	WalkScratch *no_scratch = nullptr; // (scene_intersect_wave<false> never touches it)
+	const uint32_t wt = work_item / P.split_k, part = work_item % P.split_k;
+	const bool have = wt < P.n_work;
+	const WaveTile tile = reinterpret_cast<const WaveTile *>(work)[have ? wt : 0];
+	const uint32_t per_part = (P.sample_count + P.split_k - 1u) / P.split_k;
+	const uint32_t s_lo = part * per_part < P.sample_count ? part * per_part : P.sample_count;
+	const uint32_t s_hi = s_lo + per_part < P.sample_count ? s_lo + per_part : P.sample_count;
+	const uint32_t pool_first = s_lo, pool_items = have ? (s_hi - s_lo) * 64u : 0u;
+	if (P.bounce_limit == 0u) return; // (such launches are not made: api.cpp)
+	const V3 cam_pos = ld3(P.cam_pos);
+
+	// every slot starts empty
+	pool.empty_list[lane] = (uint8_t)lane;
+	if (lane + 64u < kSortSlots) pool.empty_list[lane + 64u] = (uint8_t)(lane + 64u);
+	uint32_t n_empty = kSortSlots, n_hit = 0, next_item = 0; // wave-uniform
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	for (;;) {
+		// the launch parameters a trip needs, re-read from the kernel arguments (see render_wave)
+		KernargWords src = kernarg_params;
+		asm volatile("" : "+s"(src));
+		unsigned long long w[sizeof(RenderParams) / 8];
+#pragma unroll
+		for (unsigned i = 0; i < sizeof(RenderParams) / 8; i++) w[i] = src[i];
+		RenderParams Pt;
+		__builtin_memcpy(&Pt, w, sizeof(Pt));
+
+		// which kind of trip: shade when 64 hits wait, else start samples while the item has any, else shade what is left
+		const bool items_left = next_item < pool_items;
+		if (n_hit == 0u && !items_left) break;
+		// (a full trip of either kind when one list holds 64 slots — always, with 127 slots or more; else the longer list)
+		const bool shade_trip = n_hit >= 64u || !items_left || (n_empty < 64u && n_hit >= n_empty);
+		bool active;
+		uint32_t slot = 0, item = 0, depth = 1;
+		Rng rng;
+		rng.block = 0u, rng.lobe_bits = 0u;
+		V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1), T = mk(1.0, 1.0, 1.0);
+		bool failed = false; // lens_failed / cut: the path ends with the sample T (.) 0
+		if (shade_trip) {
+			// ---------------- SI: the next (up to) 64 parked hits
+			const uint32_t n = n_hit < 64u ? n_hit : 64u;
+			active = lane < n;
+			slot = pool.hit_list[active ? n_hit - 1u - lane : 0u];
+			n_hit -= n;
+			const uint32_t st = pool.state[slot];
+			item = pool.item[slot];
+			const uint32_t lb = pool.lobe_bits[slot];
+			rng.block = st >> 16, rng.lobe_bits = lb & 0x3FFFFFu;
+			depth = lb >> 24;
+			const DevObject &o = lobjs[active ? (st & 0xFFFFu) : 0u];
+			T = mk(pool.T[0][slot], pool.T[1][slot], pool.T[2][slot]);
+			const V3 normal = mk(pool.normal[0][slot], pool.normal[1][slot], pool.normal[2][slot]);
+			const V3 frag = mk(pool.frag[0][slot], pool.frag[1][slot], pool.frag[2][slot]);
+			const uint32_t x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
+			rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (item >> 6);
+			if (active) {
+				shade(Pt, normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, ro, rd, T);
+				depth++;
+				// (see render_wave: a path whose throughput is exactly zero is ended unless the caller traces such paths on)
+				const bool black = Pt.end_black_paths != 0u && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
+				failed = depth > Pt.bounce_limit || black;
+			}
+		} else {
+			// ---------------- GI: the work item's next 64 (pixel, sample) pairs, one per lane (slots outside a ragged tile are skipped)
+			const uint32_t n = n_empty < 64u ? n_empty : 64u;
+			item = next_item + lane;
+			next_item += n;
+			active = lane < n && item < pool_items && (item & 7u) < tile.w && ((item >> 3) & 7u) < tile.h;
+			const unsigned long long am = __ballot(active);
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+			slot = pool.empty_list[active ? n_empty - 1u - rank : 0u];
+			n_empty -= (uint32_t)__popcll(am);
+			const uint32_t x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
+			rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (item >> 6);
+			if (active) {
+				double u0, u1;
+				rng.next2(Pt.key0, Pt.key1, u0, u1); // block 0: the pixel jitter (:326-327)
+				primary_ray(Pt, x, y, u0, u1, ro, rd);
+				if (Pt.use_dof) failed = !thin_lens_from_pinhole(Pt, ro, rd, rng, ro, rd); // the reference panics there; the sample contributes zero
+			}
+		}
+		// ---------------- src/trace.rs:239 — closest hit of every lane that has a ray
+		const bool want = active && !failed;
+		double t = 0.0;
+		uint32_t sub = 0;
+		const int oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, nullptr, *no_scratch, want, ro, rd, t, sub, 0u, nullptr);
+		// ---------------- classification (the rules of render_wave's phase C)
+		bool terminal = failed, park = false;
+		V3 L = mk(0.0, 0.0, 0.0), frag = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 1.0);
+		if (want) {
+			if (oi < 0) {
+				terminal = true; // :242 miss -> radiance 0
+			} else {
+				const DevObject &o = lobjs[oi];
+				frag = ro + rd * t; // :246
+				if (o.material_kind == 2u) {
+					L = ld3(o.color); // :250-252 Emission
+					terminal = true;
+				} else {
+					if (o.geometry_kind == 0u) normal = ld3(o.normal);       // plane.rs:28-32
+					else normal = normalize(frag - ld3(o.origin));            // sphere.rs:31-35
+					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
+					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
+					const bool black_bounce = Pt.end_black_paths != 0u && (o.flags & kObjBlackDiffuse) != 0u && rng.lobe_bits < (1u << 21);
+					if ((depth == Pt.bounce_limit || black_bounce) && finite_inputs) terminal = true; // L = 0
+					else park = true;
+				}
+			}
+		}
+		if (active && terminal) { // the finished sample: T (.) L into its 32-byte sector of the per-sample buffer
+			L = hadamard(T, L);
+			RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
+			dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+		}
+		if (park) {
+			pool.frag[0][slot] = frag.x, pool.frag[1][slot] = frag.y, pool.frag[2][slot] = frag.z;
+			pool.normal[0][slot] = normal.x, pool.normal[1][slot] = normal.y, pool.normal[2][slot] = normal.z;
+			pool.T[0][slot] = T.x, pool.T[1][slot] = T.y, pool.T[2][slot] = T.z;
+			pool.state[slot] = (uint32_t)oi | (rng.block << 16); // (fewer than 2^16 objects fit the LDS; a lens loop runs at most 4096 rounds)
+			pool.lobe_bits[slot] = rng.lobe_bits | (depth << 24), pool.item[slot] = item;
+		}
+		// the slots go back: to the hit list or to the empty list
+		{
+			const unsigned long long pm = __ballot(park), em = __ballot(active && !park);
+			const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+			const uint32_t erank = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+			if (park) pool.hit_list[n_hit + prank] = (uint8_t)slot;
+			if (active && !park) pool.empty_list[n_empty + erank] = (uint8_t)slot;
+			n_hit += (uint32_t)__popcll(pm), n_empty += (uint32_t)__popcll(em);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+	}
+	finish_sample_range(P, tile, wt, lane, out);
+}
+
 // PERSIST = false: one wave per work item, block b's waves take items b * waves .. ; PERSIST = true (tile modes of grid scenes):
 // as many 16-wave workgroups as the device has CUs, each staging the masks ONCE, whose waves draw work items from a launch-wide
 // counter (P.work_counter, zeroed by the host) until none is left — the masks cost one copy per CU instead of one per
 // 4-wave workgroup, which leaves each wave 8 KB of LDS, and no wave slot idles while the rest of a workgroup finishes.
+template <int MODE, bool GRID>
+constexpr bool kSortedTrips = RMD_SORTED_TRIPS && MODE == kModeTilesBuffered && !GRID;
+// LDS of one wave of an instantiation
+template <int MODE, bool GRID>
+__host__ __device__ inline size_t wave_lds_of(uint32_t n_grids) { return kSortedTrips<MODE, GRID> ? sizeof(SortPool) : wave_lds_bytes(n_grids); }
+template <int MODE, bool GRID>
+constexpr uint32_t kPersistWaves = kSortedTrips<MODE, GRID> ? kSortedWavesPerWg : kPersistWavesPerWg;
 template <int MODE, bool GRID, bool PERSIST>
-__global__ __launch_bounds__(PERSIST ? 64 * kPersistWavesPerWg : GRID ? 64 * kGridWavesPerWg : 64, GRID ? RMD_GRID_MINW : (PERSIST ? 4 : RMD_NOGRID_MINW)) void render_kernel(
+__global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ? 64 * kGridWavesPerWg : 64,
+                             GRID ? RMD_GRID_MINW : (kSortedTrips<MODE, GRID>) ? (RMD_SORT_WAVES * RMD_SORT_WGS_PER_CU / 4) : (PERSIST ? 4 : RMD_NOGRID_MINW)) void render_kernel(
     RenderParams P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work, double *__restrict__ out,
     int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub) {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -511,7 +694,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * kPersistWavesPerWg : GRID ? 64 * kGr
 	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
 	const uint32_t tid = threadIdx.x, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
 	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
-	                          (size_t)wave * wave_lds_bytes(P.n_grids);
+	                          (size_t)wave * wave_lds_of<MODE, GRID>(P.n_grids);
 	// stage the object table and the occupancy masks: coalesced, once per workgroup
 	{
 		const double *src = reinterpret_cast<const double *>(objs);
@@ -533,11 +716,13 @@ __global__ __launch_bounds__(PERSIST ? 64 * kPersistWavesPerWg : GRID ? 64 * kGr
 			if ((tid & 63u) == 0u) item = atomicAdd(P.work_counter, 1u);
 			item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
 			if (item >= n_items) break;
-			render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
+			if constexpr (kSortedTrips<MODE, GRID>) render_wave_sorted(P, kernarg_params, objs, grids, work, out, lobjs, wave_lds, item);
+			else render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
 		}
 	} else {
 		const uint32_t unit = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
-		render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, MODE == kModeList ? unit * 64u : unit);
+		if constexpr (kSortedTrips<MODE, GRID>) render_wave_sorted(P, kernarg_params, objs, grids, work, out, lobjs, wave_lds, unit);
+		else render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, MODE == kModeList ? unit * 64u : unit);
 	}
 }
 
@@ -546,20 +731,25 @@ __global__ __launch_bounds__(PERSIST ? 64 * kPersistWavesPerWg : GRID ? 64 * kGr
 template <int MODE, bool GRID>
 inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
                                 uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub, uint32_t n_cus = 0) {
+	// LDS of a workgroup of `waves` waves of this instantiation: [object table][grid occupancy masks][per-wave area]
+	auto lds_for = [&](uint32_t waves) {
+		return (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u + (size_t)waves * wave_lds_of<MODE, GRID>(P.mask_words_total ? 1u : 0u);
+	};
 	if constexpr (MODE != kModeList) {
-		if (n_cus != 0u && P.work_counter != nullptr && render_lds_bytes(P.n_objects, P.mask_words_total, kPersistWavesPerWg) <= kLdsBudgetBytes) {
-			const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, kPersistWavesPerWg);
+		constexpr uint32_t pw = kPersistWaves<MODE, GRID>;
+		if (n_cus != 0u && P.work_counter != nullptr && lds_for(pw) <= kLdsBudgetBytes) {
+			const size_t lds = lds_for(pw);
 			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
 			                                   (int)kLdsBudgetBytes);
 			if (e != hipSuccess) return e;
-			const uint32_t wgs = (n_waves + kPersistWavesPerWg - 1u) / kPersistWavesPerWg;
-			hipLaunchKernelGGL((render_kernel<MODE, GRID, true>), dim3(wgs < n_cus ? wgs : n_cus), dim3(64u * kPersistWavesPerWg), lds, stream, P, objs, grids,
-			                   work, out, path_obj, path_sub);
+			const uint32_t wgs = (n_waves + pw - 1u) / pw, resident = n_cus * (kSortedTrips<MODE, GRID> ? RMD_SORT_WGS_PER_CU : 1u);
+			hipLaunchKernelGGL((render_kernel<MODE, GRID, true>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs, grids, work, out,
+			                   path_obj, path_sub);
 			return hipGetLastError();
 		}
 	}
 	const uint32_t wpw = render_waves_per_wg(P.n_objects, P.mask_words_total);
-	const size_t lds = render_lds_bytes(P.n_objects, P.mask_words_total, wpw);
+	const size_t lds = lds_for(wpw);
 	if (lds > 64u * 1024u) { // above the default dynamic-LDS limit: opt in on the current device (cheap, and correct per device)
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                   (int)kLdsBudgetBytes);
