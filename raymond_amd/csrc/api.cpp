@@ -472,14 +472,16 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 		k = (uint32_t)ctx->tunable[RMD_TUNE_SAMPLE_SPLIT];
 		if (k > sample_count / 4u) k = sample_count / 4u; // a forced split keeps >= 4 samples (256 pool items) per wave
 	} else if (n_wave_tiles != 0) {
-		// about 64 work items per wave slot level the tail of a launch of persistent workgroups (tools/split_sweep.py — full C3 frame:
-		// 512.8 ms at 32, 508.1 at 64 .. 128, 517.8 at 500; full C2 frame: 112.9 at 32, 112.0 at 64 .. 128, 113.6 at 256), of at least
-		// 4 samples (mesh) / 32 samples (spheres) each: the spheres kernel's items end with a release and, for a tile's last one, the ordered
-		// sum — an N-way tile share of the C2 frame (tools/shard_split.py, 1/8 of the tiles): 11.5 ms at 16 samples per item, 10.4 at 31 .. 41
-		const uint32_t waves_per_slot = 64u;
+		// Mesh kernel: about 64 work items per wave slot level the tail of a launch of persistent workgroups (tools/split_sweep.py — full C3 frame:
+		// 512.8 ms at 32, 508.1 at 64 .. 128, 517.8 at 500), of at least 4 samples each.  Spheres kernel (trips sorted by role,
+		// render_kernel.hpp): an item ends with a few ever emptier trips while its last paths finish, a release and, for a tile's last item, the
+		// ordered sum, so its items are larger — about 24 per wave slot, at least 64 samples each (round 4, full C2 frame: 52.9 ms at 3 .. 6
+		// items per wave tile, 55.2 at 9, 59.1 at 12; an N-way tile share, tools/shard_split.py: N = 8 7.4 ms at 7 .. 10, 8.5 at 16, 9.2 at 3;
+		// N = 2 27.3 at 6 .. 7, 29.0 at 2, 29.8 at 12)
+		const uint32_t waves_per_slot = has_grid ? 64u : 24u;
 		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
-		const uint32_t min_samples = has_grid ? 4u : 32u;
+		const uint32_t min_samples = has_grid ? 4u : 64u;
 		if (k > sample_count / min_samples) k = sample_count / min_samples;
 	}
 	if (k > 64u) k = 64u;

@@ -551,6 +551,10 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 	__builtin_amdgcn_wave_barrier();
 	for (;;) {
 		// the launch parameters a trip needs, re-read from the kernel arguments (see render_wave)
+#ifndef RMD_SORT_RELOAD
+#define RMD_SORT_RELOAD 1
+#endif
+#if RMD_SORT_RELOAD
 		KernargWords src = kernarg_params;
 		asm volatile("" : "+s"(src));
 		unsigned long long w[sizeof(RenderParams) / 8];
@@ -558,6 +562,9 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		for (unsigned i = 0; i < sizeof(RenderParams) / 8; i++) w[i] = src[i];
 		RenderParams Pt;
 		__builtin_memcpy(&Pt, w, sizeof(Pt));
+#else
+		const RenderParams &Pt = P;
+#endif
 
 		// which kind of trip: shade when 64 hits wait, else start samples while the item has any, else shade what is left
 		const bool items_left = next_item < pool_items;

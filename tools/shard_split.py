@@ -9,7 +9,7 @@ tiles = generate_tiles(cam.backbuffer_width, cam.backbuffer_height, st.tile_size
 share = shard.shard_tiles(tiles, 0, n)
 with render.Context(0) as ctx:
     ds = render.DeviceScene(ctx, sc); fb = render.Framebuffer(ctx, cam.backbuffer_width, cam.backbuffer_height)
-    for k in (0, 4, 6, 8, 12, 16, 24, 31, 48, 64):
+    for k in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16):
         ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, k)
         best = 1e9
         for _ in range(3):
