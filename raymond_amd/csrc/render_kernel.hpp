@@ -547,6 +547,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 	pool.empty_list[lane] = (uint8_t)lane;
 	if (lane + 64u < kSortSlots) pool.empty_list[lane + 64u] = (uint8_t)(lane + 64u);
 	uint32_t n_empty = kSortSlots, n_hit = 0, next_item = 0; // wave-uniform
+	unsigned long long trips_left = (unsigned long long)pool_items * 20u + 64u; // (a path has at most RMD_MAX_BOUNCE_LIMIT = 16 segments)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	for (;;) {
@@ -569,6 +570,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		// which kind of trip: shade when 64 hits wait, else start samples while the item has any, else shade what is left
 		const bool items_left = next_item < pool_items;
 		if (n_hit == 0u && !items_left) break;
+		if (trips_left-- == 0ull) break; // (never reached: every trip hands out a pair or advances a path by a segment — the bound gives the wave an exit whatever happens)
 		// (a full trip of either kind when one list holds 64 slots — always, with 127 slots or more; else the longer list)
 		const bool shade_trip = n_hit >= 64u || !items_left || (n_empty < 64u && n_hit >= n_empty);
 		bool active;
