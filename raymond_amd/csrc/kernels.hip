@@ -1,15 +1,15 @@
 // HIP kernels of the radiance integrator for gfx950 (CDNA4).
 //
-// render_kernel<MODE=tiles|tiles-buffered, GRID, PERSIST> — the hot path.  One wavefront (64 lanes) per 8x8 pixel tile, lane = pixel
-//   (split launches: per (tile, sample range) work item, lanes drawing (pixel, sample) pairs from the wave's pool; grid scenes:
-//   persistent 16-wave workgroups whose waves draw the work items from a counter).
-//   Each lane runs the reference's per-pixel loop (src/trace.rs:197-205) for `sample_count` consecutive samples as an
-//   iterative state machine: a lane whose path ends regenerates the next sample's primary ray in place (in-lane path
-//   regeneration), so the wave stays full until the last samples.  trace()'s recursion (src/trace.rs:232-320) becomes a
-//   running throughput: each bounce's weight is multiplied in when it is produced and the terminal radiance is scaled by
-//   the product.  The object table is staged into LDS once per workgroup (coalesced); the uniform
-//   closest-hit loop reads it through scalar loads, the divergent post-hit lookup reads the LDS copy.  GRID = true adds
-//   the wave-cooperative grid walk (grid_walk.hpp) and shares the grids' occupancy masks through LDS.
+// render_kernel<MODE=tiles|tiles-buffered, GRID, PERSIST> — the hot path (render_kernel.hpp).  Persistent 16-wave workgroups, one per CU, whose
+//   waves draw (8x8 wave tile, sample range) work items from a counter.  trace()'s recursion (src/trace.rs:232-320) becomes a running
+//   throughput: each bounce's weight is multiplied in when it is produced and the terminal radiance is scaled by the product (DESIGN.md
+//   section 3).  The object table is staged into LDS once per workgroup; the uniform closest-hit loop reads it through scalar loads, the
+//   divergent post-hit lookup reads the LDS copy.  Two wave bodies:
+//     render_wave_sorted (split launches of scenes without grids — the spheres kernel): the wave's paths live in a pool of slots in LDS and a trip is
+//       64 new samples (primary ray, intersection, classification) or 64 parked hits (shading, intersection, classification): every lane
+//       of a trip needs the same thing;
+//     render_wave (everything else): a lane keeps its path and regenerates the next sample's primary ray in place; GRID = true adds the
+//       wave-cooperative grid walk (grid_walk.hpp) and shares the grids' occupancy masks through LDS.
 //   MFMA is not used: there is no dense contraction anywhere on this path.
 // (The kernel template itself is in render_kernel.hpp; its list instantiation — an explicit (x, y, sample) per lane, for the
 // parity probes — and the probe kernels are compiled into libraymond_hip_probe.so from probe_kernels.hip, not into this library.)

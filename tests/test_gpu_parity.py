@@ -785,6 +785,38 @@ def test_sample_split_is_bit_exact(gpu_ctx, small_mesh_scene):
         fb.close(), ds.close()
 
 
+@pytest.mark.parametrize("dof,bounces,trace", [(False, 5, False), (True, 8, False), (False, 3, True), (True, 1, False)])
+def test_role_sorted_trips_equal_the_lane_per_path_kernel(gpu_ctx, oracle, dof, bounces, trace):
+    """The spheres kernel's split launches run trips sorted by role (render_kernel.hpp: render_wave_sorted — a wave's paths in an LDS pool, a trip
+    is 64 new samples or 64 hits to shade); unsplit launches run the lane-per-path form.  Same frame bit for bit — ragged edge tiles
+    (203 x 117), thin lens on and off, bounce limits 1 / 3 / 5 / 8, zero-throughput paths ended or traced, several sample splits incl. ones
+    that do not divide the sample count, += on a pre-filled buffer — and equal to the oracle's."""
+    W, H, spp = 203, 117, 29
+    sc = scenes.reflective_spheres()
+    st = Settings(scenes.camera(W, H, aperture_radius=0.5 if dof else 0.0), sample_count=spp, bounce_limit=bounces, seed=91, use_dof=dof, trace_black_paths=trace)
+    cam = st.camera_settings
+    tiles = generate_tiles(W, H, (32, 32))
+    base = np.random.default_rng(8).uniform(0, 1, (H, W, 3))
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    frames = {}
+    for k in (1, 2, 3, 7):
+        gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, k)
+        try:
+            fb.upload(base)
+            render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+            assert gpu_ctx.last_launch_info().split_k == k
+            frames[k] = fb.download()
+        finally:
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0)
+    fb.close(), ds.close()
+    for k in (2, 3, 7):
+        assert frames[k].tobytes() == frames[1].tobytes(), "split %d (role-sorted trips) differs from the lane-per-path kernel" % k
+    ref = oracle.OracleScene(sc).render_tiles(cam, st, tiles, accum=base.copy(), threads=4)
+    ok = rel_close(frames[3], ref, 1e-9).all(axis=2)
+    assert ok.mean() >= 0.995, (~ok).sum()
+
+
 def test_walk_batching_does_not_change_the_image(gpu_ctx, small_mesh_scene):
     """Grid scenes: a lane whose ray enters a grid's box waits until enough lanes of its wave need a walk (kernels.hip,
     RenderParams::walk_batch).  That is scheduling only — the closest hit is the lexicographic minimum of (distance,
