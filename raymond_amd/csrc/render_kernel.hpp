@@ -745,7 +745,9 @@ inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const
 		return (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u + (size_t)waves * wave_lds_of<MODE, GRID>(P.mask_words_total ? 1u : 0u);
 	};
 	if constexpr (MODE != kModeList) {
-		constexpr uint32_t pw = kPersistWaves<MODE, GRID>;
+		uint32_t pw = kPersistWaves<MODE, GRID>;
+		if constexpr (kSortedTrips<MODE, GRID>)
+			while (pw > 4u && lds_for(pw) > kLdsBudgetBytes) pw--; // a large object table leaves room for fewer pools: fewer waves per workgroup
 		if (n_cus != 0u && P.work_counter != nullptr && lds_for(pw) <= kLdsBudgetBytes) {
 			const size_t lds = lds_for(pw);
 			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>), hipFuncAttributeMaxDynamicSharedMemorySize,

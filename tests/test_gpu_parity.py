@@ -817,6 +817,42 @@ def test_role_sorted_trips_equal_the_lane_per_path_kernel(gpu_ctx, oracle, dof, 
     assert ok.mean() >= 0.995, (~ok).sum()
 
 
+@pytest.mark.parametrize("n_spheres", [150, 900])
+def test_role_sorted_trips_with_a_large_object_table(gpu_ctx, oracle, n_spheres):
+    """A scene of many objects leaves the persistent workgroups of the spheres kernel room for fewer LDS pools (150 spheres: 14 waves per
+    workgroup; 900: none — the launch falls back to one wave per work item): same frame as the lane-per-path kernel bit for bit in every
+    launch form, and the oracle's."""
+    from raymond_amd.scene import Material, Object, Scene, Sphere
+
+    rng = np.random.default_rng(n_spheres)
+    sc = Scene()
+    for i in range(n_spheres):
+        c = (rng.uniform(-1.8, 1.8), rng.uniform(-0.9, 1.8), rng.uniform(1.5, 4.8))
+        mat = Material.Metal(tuple(rng.uniform(0.2, 1.0, 3)), 0.05) if i % 3 == 0 else Material.Diffuse(tuple(rng.uniform(0.0, 1.0, 3)), 0.3)
+        sc.objects.append(Object(Sphere(c, rng.uniform(0.03, 0.12)), mat))
+    sc.objects.extend(scenes._room_planes())
+    W, H, spp = 96, 64, 12
+    st = Settings(scenes.camera(W, H), sample_count=spp, bounce_limit=4, seed=5)
+    cam = st.camera_settings
+    tiles = generate_tiles(W, H, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, sc)
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    frames = {}
+    for split, form in ((1, 0), (3, 0), (3, 2), (2, 1)):
+        gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, form)
+        try:
+            fb.zero()
+            render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+            frames[(split, form)] = fb.download()
+        finally:
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, 0)
+    fb.close(), ds.close()
+    for key, img in frames.items():
+        assert img.tobytes() == frames[(1, 0)].tobytes(), key
+    ref = oracle.OracleScene(sc).render_tiles(cam, st, tiles, threads=4)
+    assert rel_close(frames[(3, 2)], ref, 1e-9).all(axis=2).mean() >= 0.995
+
+
 def test_walk_batching_does_not_change_the_image(gpu_ctx, small_mesh_scene):
     """Grid scenes: a lane whose ray enters a grid's box waits until enough lanes of its wave need a walk (kernels.hip,
     RenderParams::walk_batch).  That is scheduling only — the closest hit is the lexicographic minimum of (distance,
