@@ -90,11 +90,11 @@ def test_spot_pixels_of_the_production_kernel_at_full_size(gpu_ctx, oracle, drag
     assert np.abs(got - acc)[~ok].max(initial=0.0) <= spp * 1.5 * 4
 
 
-@pytest.mark.parametrize("config,spp,mode", [("C2", 128, "default"), ("C3", 16, "default"), ("C3", 16, "end")])
-def test_whole_1080p_frame_of_the_production_kernel_against_the_oracle(gpu_ctx, oracle, dragon, config, spp, mode):
-    """EVERY pixel of a 1920x1080 frame rendered by the production instantiation (asserted through rmd_last_launch_info: persistent workgroups,
+@pytest.mark.parametrize("config,spp,mode", [("C2", 128, "default"), ("C3", 16, "default"), ("C3", 16, "end"), ("C4", 8, "default"), ("C5", 8, "default")])
+def test_whole_frame_of_the_production_kernel_against_the_oracle(gpu_ctx, oracle, dragon, config, spp, mode):
+    """EVERY pixel of a full-size frame (1920x1080; C4: 3840x2160, 8 bounces; C5: thin lens) rendered by the production instantiation (asserted through rmd_last_launch_info: persistent workgroups,
     samples split over several work items, pooled hand-out, ordered sum) against `oracle.render_tiles` — the reference's loop
-    (src/trace.rs:197-205) on 16 host threads: >= 99.5 % of the 2,073,600 pixels within 1e-9, the rest off by whole samples (an ulp-level
+    (src/trace.rs:197-205) on 16 host threads: >= 99.5 % of the pixels within 1e-9, the rest off by whole samples (an ulp-level
     difference that changed a hit sequence), mean radiance equal to 1e-4.  C2: 265.4 M samples (the spheres kernel splits a tile's samples from 128 per pixel on), flags 0 (zero-throughput paths ended: the scene has
     no grid); C3: 33.2 M samples with flags 0 (every path traced) and with RMD_RENDER_END_BLACK_PATHS."""
     st = scenes.config_settings(config, spp=spp)
