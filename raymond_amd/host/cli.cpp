@@ -1,7 +1,7 @@
 // raymond_cli — the executable caller of the host mirror; follows cli_old/src/main.rs:35-198
 // (build scene -> Settings -> render_tiled -> await -> tone-map -> image file).
 //
-//   raymond_cli render <spheres|dragon[:n]> W H SPP BOUNCES out.ppm [--raw out.f64] [--gpus N] [--spi K] [--aperture R]
+//   raymond_cli render <spheres|dragon[:n]> W H SPP BOUNCES out.ppm [--raw out.f64] [--gpus N] [--spi K] [--aperture R] [--end-black-paths 1]
 //   raymond_cli mesh N out.bin            procedural stand-in mesh as raw f64 (tri_pos then tri_nrm)
 //   raymond_cli ply in.ply out.bin        Mesh::load_ply + bake_transform(0,-0.3,2.9), raw f64 as above
 //   raymond_cli tiles W H TW TH           tile generation order of render_tiled, one "left top width height" per line
@@ -90,6 +90,7 @@ int main(int argc, char **argv) {
 				else if (!std::strcmp(argv[i], "--gpus")) st.worker_count = std::atoi(argv[i + 1]);
 				else if (!std::strcmp(argv[i], "--spi")) st.samples_per_iteration = std::atoi(argv[i + 1]);
 				else if (!std::strcmp(argv[i], "--aperture")) st.camera_settings.aperture_radius = std::atof(argv[i + 1]), st.use_dof = true;
+				else if (!std::strcmp(argv[i], "--end-black-paths")) st.end_black_paths = std::atoi(argv[i + 1]) != 0; // opt-in on mesh scenes (raymond_hip.h)
 			}
 			Scene scene;
 			if (what == "spheres") scene = reflective_spheres();
