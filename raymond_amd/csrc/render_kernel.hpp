@@ -100,13 +100,36 @@ enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
 #ifndef RMD_TRIP_RELOAD
 #define RMD_TRIP_RELOAD 1
 #endif
+// A finished sample into its 32-byte sector of the per-sample buffer (spheres kernel).  Plain stores; the end of a work item releases them at
+// agent scope (finish_sample_range) — on this part that writes back every dirty line of the XCD's L2 (buffer_wbl2) and is what a work item
+// costs at its end: 66.4 ms per C2 frame at 16 items per wave tile against 53.5 at 4, 53.4 / 53.3 with the fence taken out (timing only).
+// RMD_SAMPLE_STORE_WT = 1 is the measured alternative: two WRITE-THROUGH stores (sc1: the data goes to memory at once and leaves no dirty line),
+// the wave then only waits for its own stores (vmcnt(0)) before it bumps the tile's counter.  Bit-identical (all tests, tools/stress_sum.py), the
+// frame time no longer depends on the item size (54.2 ms at 7 .. 16 items per wave tile) — but the full frame is 1.3 % slower than plain stores at
+// their best item size (same box: 54.2 vs 53.5 ms; an N = 8 tile share 7.16 vs 7.42 ms): the default stays plain stores + release.
+#ifndef RMD_SAMPLE_STORE_WT
+#define RMD_SAMPLE_STORE_WT 0
+#endif
+RMD_DEV void store_sample(RMD_GLOBAL double *dst, V3 L) {
+#if RMD_SAMPLE_STORE_WT
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	const d2 xy = {L.x, L.y};
+	asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1" : : "v"(dst), "v"(xy), "v"(L.z) : "memory");
+#else
+	dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+#endif
+}
 // The end of a (wave tile, sample range) work item of the spheres kernel: the wave that finishes a wave tile's LAST sample range adds the tile's
 // samples to the pixels, strictly in sample order (src/trace.rs:203: the reference's sequential sum, bit for bit) — inside the render kernel, where
 // the reads (bandwidth) overlap the other waves' arithmetic; as a kernel of its own the sum cost 5.5 ms per 1080p / 500 spp frame.  Release: an
 // agent-scope fence writes this wave's sample stores back before its count; acquire: the last wave invalidates its caches before it reads.
 RMD_DEV void finish_sample_range(const RenderParams &P, const WaveTile &tile, uint32_t wt, uint32_t lane, double *__restrict__ out) {
 	if (P.tile_done == nullptr || wt >= P.n_work) return;
+#if RMD_SAMPLE_STORE_WT
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through sample stores have reached memory before its count is seen
+#else
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's samples leave the XCD's L2 before its count is seen
+#endif
 	uint32_t before = 0;
 	if (lane == 0u) before = __hip_atomic_fetch_add(P.tile_done + wt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
@@ -350,7 +373,8 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 				// plain stores: when a wave of this kernel adds the tile's samples (below) — it may run on another XCD, whose L2 does not see this
 				// one's dirty lines — the release in front of the tile's counter writes them back, once per work item (round 2 wrote every
 				// sample through with three 8-byte agent-scope stores: 96 bytes at the memory side per 24-byte sample)
-				dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+				if constexpr (GRID) dst[0] = L.x, dst[1] = L.y, dst[2] = L.z; // (added by sum_kernel, behind the kernel boundary)
+				else store_sample(dst, L);                                  // (added by a wave of this kernel: finish_sample_range)
 			} else {
 				if constexpr (acc_in_memory) {
 					RMD_GLOBAL double *px = (RMD_GLOBAL double *)out + ((size_t)(tile.x0 + (lane & 7u)) + (size_t)(tile.y0 + (lane >> 3)) * Pt.W) * 3;
@@ -653,7 +677,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		if (active && terminal) { // the finished sample: T (.) L into its 32-byte sector of the per-sample buffer
 			L = hadamard(T, L);
 			RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
-			dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+			store_sample(dst, L);
 		}
 		if (park) {
 			pool.frag[0][slot] = frag.x, pool.frag[1][slot] = frag.y, pool.frag[2][slot] = frag.z;
