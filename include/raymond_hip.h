@@ -204,7 +204,9 @@ enum {
 	RMD_TUNE_SCRATCH_CAP_MB = 4, /* RMD_SCRATCH_CAP_MB: cap of the per-sample scratch of split launches, MiB (0 = an eighth of the
 	                              device memory that is free when the buffer is (re)allocated); a launch whose samples do not fit —
 	                              or whose buffer the device cannot provide — runs as several passes                       */
-	RMD_TUNE_COUNT = 5
+	RMD_TUNE_WALK_CUT = 5,     /* RMD_WALK_CUT: K + 1, where a grid-walk call of a wave stops stepping under its last K rays and leaves their
+	                              walks to the wave's next call (0 = the library's choice, K = 4; 1 = every call finishes every walk)      */
+	RMD_TUNE_COUNT = 6
 };
 /* Free and total memory of the context's device, bytes (hipMemGetInfo): what a host that shares the GPU sizes its launches by. */
 rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, uint64_t *out_total_bytes);

@@ -1,6 +1,7 @@
 // C-ABI implementation (include/raymond_hip.h): contexts, scene upload, the render entry points,
 // framebuffer helpers and the resolve/tone-map epilogue.  Host code only; kernels are in kernels.hip.
 #define RMD_WITH_HIP 1
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +66,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_WALK_BATCH] = env_int("RMD_WALK_BATCH");
 		ctx->tunable[RMD_TUNE_MASK_BUDGET] = env_int("RMD_MASK_BUDGET");
 		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
+		ctx->tunable[RMD_TUNE_WALK_CUT] = env_int("RMD_WALK_CUT");
 		const char *form = std::getenv("RMD_LAUNCH_FORM");
 		ctx->tunable[RMD_TUNE_LAUNCH_FORM] = !form ? 0 : (std::strcmp(form, "per-item") == 0 || std::strcmp(form, "1") == 0) ? 1 : (std::strcmp(form, "persistent") == 0 || std::strcmp(form, "2") == 0) ? 2 : 0;
 #if RMD_DIAG
@@ -169,6 +171,13 @@ RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const r
 	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : ((st->flags & RMD_RENDER_END_BLACK_PATHS) || !scene || scene->n_grids == 0u) ? 1u : 0u;
 	P.walk_batch = rmd::kWalkBatchDefault;
 	if (ctx && ctx->tunable[RMD_TUNE_WALK_BATCH] > 0) P.walk_batch = (uint32_t)ctx->tunable[RMD_TUNE_WALK_BATCH]; // any value gives the same image
+	// walks put aside for the wave's next walk call (grid_walk.hpp): the carried state is ONE walk's, so only in scenes with one grid object.
+	// Low byte: a round's stepping ends under its last K lanes; next byte: a call ends when at most 2K lanes are still walking.
+	{
+		uint32_t k = rmd::kWalkCutDefault;
+		if (ctx && ctx->tunable[RMD_TUNE_WALK_CUT] > 0) k = (uint32_t)std::min<int64_t>(ctx->tunable[RMD_TUNE_WALK_CUT] - 1, 31); // any value gives the same image
+		P.walk_cut = (scene && scene->n_grid_objects == 1u) ? (k | (2u * k) << 8) : 0u;
+	}
 #if RMD_DIAG
 	if (ctx) P.debug_flags = ctx->debug_flags;
 #endif
@@ -246,6 +255,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 	rmd_scene *sc = new (std::nothrow) rmd_scene();
 	if (!sc) return rmd::fail(ctx, RMD_ERR_OUT_OF_MEMORY, "rmd_scene_create: allocation failed");
 	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids;
+	for (uint32_t i = 0; i < n_objects; i++) sc->n_grid_objects += objects[i].geometry_kind == RMD_GEOM_GRID ? 1u : 0u;
 	auto upload = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
 		*dst = nullptr;
 		hipError_t e = hipMalloc(dst, bytes ? bytes : 16);

@@ -105,7 +105,7 @@ struct RenderParams {
 	uint32_t *work_counter;             // persistent launches: the next work item (zeroed by the host before the launch)
 	uint32_t *tile_done;                // split launches: finished waves per wave tile (zeroed by the host); the last one adds the tile's samples
 	uint32_t end_black_paths;           // 1: a path whose throughput is exactly (0, 0, 0) is ended — scenes without grids unless RMD_RENDER_TRACE_BLACK_PATHS, scenes with grids only with RMD_RENDER_END_BLACK_PATHS (api.cpp: make_params)
-	uint32_t _pad_params;
+	uint32_t walk_cut;                  // K: a walk call puts the walks of its last K lanes aside for the wave's next call (grid_walk.hpp); 0 = never.  Any value gives the same image
 };
 
 // List mode (probe): one lane per explicit (x, y, sample).

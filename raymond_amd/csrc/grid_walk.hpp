@@ -127,6 +127,14 @@ struct alignas(16) WalkScratch {
 	uint32_t marker[64];            // per 64-test chunk: lane + 1 of the lane whose tests begin at that position
 };
 
+// A walk that is put aside in the middle and taken up again by the wave's NEXT walk call (grid_intersect_wave: `cut_lanes`): the state of the
+// ray's DDA — everything the stepping changes; the per-ray constants (t_delta, index strides) are derived from the ray again.  One column per lane.
+struct alignas(16) WalkCarry {
+	double tm[3][64];
+	uint32_t idx[64], prev[64];
+	uint32_t rem[3][64];
+};
+
 // One DDA step (see above): three compares, the three axis masks on the scalar unit, and each axis' {t_max += t_delta;
 // counter -= 1; index += stride} under its mask — 12 vector instructions, no branches (the compiler's rendering of the same C++
 // re-evaluates a compare, routes the stride through a select and branches around two blocks).  exec is saved in %[sv] and
@@ -196,7 +204,7 @@ template <bool LEAN>
 RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shift, uint32_t mask_pad_bit, uint32_t idx_limit, WalkScratch &scr,
                                     uint32_t lane, bool &walking, uint32_t &n_cand, uint32_t &idx, uint32_t &prev, uint32_t &remx, uint32_t &remy, uint32_t &remz,
                                     double &tmx, double &tmy, double &tmz, double tdx, double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz,
-                                    [[maybe_unused]] unsigned long long *dbg = nullptr) {
+                                    uint32_t cut_lanes, [[maybe_unused]] unsigned long long *dbg = nullptr) {
 	uint32_t budget = 0x7FFFFFFFu;
 #if RMD_DIAG
 	if (dbg) scr.marker[0] = 0u; // DIAG: set once a lane of the wave has a candidate in this round
@@ -226,6 +234,7 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 #endif
 		}
 		prev = here;
+		if ((uint32_t)__popcll(__ballot(walking && budget != 0u)) <= cut_lanes) break; // (0: the loop's own condition) the stragglers go on in a later round or call
 	}
 }
 
@@ -304,8 +313,10 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 	    "s_or_b64 s[90:91], s[90:91], vcc\n" \
 	    "Lrmd_dda_nocand%=:\n\t" \
 	    "s_andn2_b64 s[94:95], s[94:95], s[90:91]\n\t" \
+	    "s_bcnt1_i32_b64 s98, s[94:95]\n\t" \
 	    "s_mov_b64 exec, s[94:95]\n\t" \
-	    "s_cbranch_execnz Lrmd_dda_loop%=\n\t" \
+	    "s_cmp_gt_u32 s98, %[cut]\n\t"                     /* go on while more than `cut` lanes are stepping (0: until none is) */ \
+	    "s_cbranch_scc1 Lrmd_dda_loop%=\n\t" \
 	    "s_mov_b64 exec, s[86:87]\n\t" \
 	    "v_mov_b32 %[bit], 0\n\t" \
 	    "s_and_b64 exec, s[88:89], s[86:87]\n\t" \
@@ -318,15 +329,16 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 	    : [tmx] "+v"(tmx), [tmy] "+v"(tmy), [tmz] "+v"(tmz), [idx] "+v"(idx), [prev] "+v"(prev), [rx] "+v"(remx), [ry] "+v"(remy), [rz] "+v"(remz), \
 	      [caddr] "+v"(caddr), [bit] "=&v"(bit), [word] "=&v"(word), [budget] "=&v"(budget), [cleft] "=&v"(cleft) \
 	    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [dix] "v"(dix), [diy] "v"(diy), [diz] "v"(diz), [pad] "s"(mask_pad_bit), [mbase] "s"(mask_base), \
-	      [limit] "s"(idx_limit), [ncand1] "n"(RMD_WALK_CANDIDATES - 1), [look1] "n"(RMD_WALK_LOOKAHEAD - 1), [firstoff] "n"(sizeof(WalkScratch::start)) \
-	    : "vcc", "scc", "memory", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
+	      [limit] "s"(idx_limit), [cut] "s"(cut_lanes), [ncand1] "n"(RMD_WALK_CANDIDATES - 1), [look1] "n"(RMD_WALK_LOOKAHEAD - 1), \
+	      [firstoff] "n"(sizeof(WalkScratch::start)) \
+	    : "vcc", "scc", "memory", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98");
 // LEAN (uniform per round): the mask holds a bit for every cell of the array, every cell inside the grid has an index inside the array
 // (res.z <= res.y) and no lane of the wave started from a cell outside the grid (Q6): the index then needs neither the clamp to the mask's zero
 // word nor the test against the end of the array — 19 + 13 instructions per step for 20 + 15.
 template <bool LEAN>
 RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bit, uint32_t idx_limit, uint32_t cand_base, bool &walking, uint32_t &n_cand,
                                              uint32_t &idx, uint32_t &prev, uint32_t &remx, uint32_t &remy, uint32_t &remz, double &tmx, double &tmy, double &tmz,
-                                             double tdx, double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz) {
+                                             double tdx, double tdy, double tdz, int32_t dix, int32_t diy, int32_t diz, uint32_t cut_lanes) {
 	uint32_t caddr = cand_base, bit, word, budget, cleft;
 	if constexpr (LEAN) {
 		RMD_DDA_LOOP_ASM("v_lshrrev_b32 %[word], 5, %[idx]\n\t", "%[prev]" /* the index before the step */, "", "")
@@ -341,8 +353,17 @@ RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bi
 // Must be called by all 64 lanes of the wave in uniform control flow; `want` selects the lanes that have a ray.
 // lds_mask: occupancy bits of this grid in LDS (bit i covers cells [i << shift, (i+1) << shift)).
 // scr: this wave's scratch in LDS.
+//
+// Walks put aside (cut_lanes > 0, with `carry` = this wave's WalkCarry): a walk call lasts as long as its longest ray — ~85 steps where the
+// average ray needs 26 — and most of a call's stepping iterations serve a handful of lanes.  With cut_lanes = K a round's stepping ends once at
+// most K lanes are still stepping, and a call ends once at most K lanes are still walking; a lane whose walk is unfinished then stores its DDA
+// state (`carried` comes back true, no result) and the caller presents the SAME ray again at the wave's next walk call with `carried` set, where the
+// walk goes on from that state beside the new rays.  The steps, candidates and tests of every ray are those of an uninterrupted walk, in the
+// same order: the result is the same.  The caller passes K > 0 only for calls with many more than K walkers (every call then advances every
+// walker by at least a step) and K = 0 when the wave has nothing else to do, which finishes every walk.
 RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, WalkScratch &scr, bool want, V3 ro, V3 rd, bool &hit_out,
-                                 double &t_out, uint32_t &tri_out, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr) {
+                                 double &t_out, uint32_t &tri_out, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr, uint32_t cut_lanes = 0u,
+                                 WalkCarry *carry = nullptr, bool *carried = nullptr, uint32_t cut_round = 0u) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const int32_t rx = (int32_t)g.res[0], ry = (int32_t)g.res[1], rz = (int32_t)g.res[2];
 	const uint64_t resx = g.res[0], resz = g.res[2], n_cells = g.n_cells;
@@ -422,6 +443,22 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		}
 	}
 
+	if (carried) {
+		if (*carried && walking) { // the walk goes on where the previous call left it
+			tmx = carry->tm[0][lane], tmy = carry->tm[1][lane], tmz = carry->tm[2][lane];
+			idx = carry->idx[lane], prev = carry->prev[lane];
+			remx = carry->rem[0][lane], remy = carry->rem[1][lane], remz = carry->rem[2][lane];
+		}
+		*carried = false;
+	}
+	auto put_aside = [&]() {
+		carry->tm[0][lane] = tmx, carry->tm[1][lane] = tmy, carry->tm[2][lane] = tmz;
+		carry->idx[lane] = idx, carry->prev[lane] = prev;
+		carry->rem[0][lane] = remx, carry->rem[1][lane] = remy, carry->rem[2][lane] = remz;
+		*carried = true;
+		walking = false;
+	};
+
 	bool found = false;
 	double found_t = 0.0;
 	uint32_t found_tri = 0;
@@ -457,17 +494,18 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			if (lean) {
 				if (walking)
 					dda_collect_candidates_asm<true>((uint32_t)(uintptr_t)lds_mask, mask_pad_bit, idx_limit, (uint32_t)(uintptr_t)&scr.start[lane], walking, n_cand, idx,
-					                                 prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+					                                 prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, cut_lanes);
 			} else if (walking)
 				dda_collect_candidates_asm<false>((uint32_t)(uintptr_t)lds_mask, mask_pad_bit, idx_limit, (uint32_t)(uintptr_t)&scr.start[lane], walking, n_cand, idx,
-				                                  prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+				                                  prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, cut_lanes);
 		}
 #else
 		const bool lean = lean_grid && __ballot(walking && start_outside) == 0ull;
-		if (lean) dda_collect_candidates<true>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz);
+		if (lean) dda_collect_candidates<true>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, cut_lanes);
 #endif
-		else dda_collect_candidates<false>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, count_events ? dbg : nullptr);
+		else dda_collect_candidates<false>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, cut_lanes, count_events ? dbg : nullptr);
 		RMD_STAMP(1)
+		if (cut_lanes != 0u && walking && n_cand == 0u) put_aside(); // the stepping was cut short under a lane that has found nothing to test yet
 		if (__ballot(n_cand != 0u) == 0ull) {
 			if (__ballot(walking) == 0ull) break;
 			continue; // look-ahead budget used up without a candidate: keep stepping
@@ -599,7 +637,12 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			found_tri = closest_tri;
 			walking = false;
 		}
-		if (__ballot(walking) == 0ull) break;
+		const unsigned long long still = __ballot(walking);
+		if (still == 0ull) break;
+		if ((uint32_t)__popcll(still) <= cut_round) { // not worth another round: these walks go on in the wave's next call
+			if (walking) put_aside();
+			break;
+		}
 	}
 	RMD_STAMP(7)
 #if RMD_DIAG

@@ -48,6 +48,7 @@ struct rmd_context {
 struct rmd_scene {
 	rmd_context *ctx = nullptr;
 	uint32_t n_objects = 0, n_grids = 0;
+	uint32_t n_grid_objects = 0; // objects whose geometry is a grid
 	uint32_t mask_words_total = 0; // LDS words of the grids' occupancy masks
 	rmd::DevObject *d_objects = nullptr;
 	rmd::DevGrid *d_grids = nullptr;

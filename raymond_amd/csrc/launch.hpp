@@ -39,6 +39,8 @@ constexpr size_t kMaskBudgetBytes = 48u * 1024u;
 constexpr uint32_t kSampleStride = 4;
 // walk batching (kernels.hip): lanes of a wave that must be waiting for a grid walk before one is run
 constexpr uint32_t kWalkBatchDefault = 40;
+// walks put aside (grid_walk.hpp: cut_lanes): a walk call leaves its last K walkers to the wave's next call
+constexpr uint32_t kWalkCutDefault = 4;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
 constexpr double kMaxRoughness = 512.0;
 // waves per workgroup of the grid instantiation (they share the LDS occupancy masks)

@@ -12,7 +12,8 @@ namespace rmd {
 
 // LDS per wave: the cooperative-walk scratch, only when the scene has grids.
 // per-wave LDS of the grid kernel: the walk scratch and the 64 paths' throughput (3 doubles per lane)
-__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) : 0; }
+// ... and the DDA states of walks put aside for the wave's next walk call (grid_walk.hpp: WalkCarry)
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) + sizeof(WalkCarry) : 0; }
 
 // Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
 // reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
@@ -83,6 +84,16 @@ constexpr uint32_t kWalkMinRunnable = RMD_WALK_MIN_RUNNABLE;
 #define RMD_WALK_MAX_WAIT 6
 #endif
 constexpr uint32_t kWalkMaxWait = RMD_WALK_MAX_WAIT;
+// walks put aside (grid_walk.hpp: cut_lanes = RenderParams::walk_cut): only in calls with at least this many walkers ...
+#ifndef RMD_WALK_CUT_MIN_WALKERS
+#define RMD_WALK_CUT_MIN_WALKERS 16
+#endif
+constexpr uint32_t kWalkCutMinWalkers = RMD_WALK_CUT_MIN_WALKERS;
+// ... while at least this many lanes of the wave have something else to do
+#ifndef RMD_WALK_CUT_MIN_RUNNABLE
+#define RMD_WALK_CUT_MIN_RUNNABLE 0
+#endif
+constexpr uint32_t kWalkCutMinRunnable = RMD_WALK_CUT_MIN_RUNNABLE;
 
 // Occupancy targets (waves per SIMD), measured on MI355X: the grid walk is latency-bound and gains 1.6x from 4 waves/SIMD
 // (128 VGPRs, a few dozen spills) over 2; the grid-less kernel is VALU-bound and is fastest at 3 (168 VGPRs).
@@ -260,6 +271,8 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 	static_assert(!GRID || sizeof(WalkScratch) >= 256u * sizeof(double) + 64u * sizeof(int32_t), "the walk scratch holds a wave's parked hits");
 	// grid scenes: a ray's closest plane/sphere hit while the lane waits for the walk that settles the grids (see intersect_simple)
 	bool new_ray = false, waiting = false;
+	bool carried = false; // ... and its walk has begun: put aside by the previous walk call, to be taken up by the next (grid_walk.hpp)
+	[[maybe_unused]] WalkCarry *carry = GRID ? reinterpret_cast<WalkCarry *>(wave_lds + sizeof(WalkScratch) + 64u * 3u * sizeof(double)) : nullptr;
 	uint32_t trips_since_walk = 0; // wave-uniform
 	double part_t = kFMax;
 	int part_obj = -1;
@@ -491,8 +504,13 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			trips_since_walk++;
 			if (wm != 0ull && ((uint32_t)__popcll(wm) >= Pt.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
 				trips_since_walk = 0;
-				intersect_grids(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters);
-				waiting = false;
+				// walks are put aside only by a call with many walkers in a wave that has other lanes to run: otherwise every walk is finished
+				const uint32_t n_walkers = (uint32_t)__popcll(wm);
+				const bool cut = n_walkers >= kWalkCutMinWalkers && (uint32_t)__popcll(rm) >= kWalkCutMinRunnable;
+				const uint32_t cut_lanes = cut ? Pt.walk_cut & 0xffu : 0u, cut_round = cut ? (Pt.walk_cut >> 8) & 0xffu : 0u;
+				intersect_grids(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters,
+				                cut_lanes, carry, &carried, cut_round);
+				waiting = carried;
 			}
 			RMD_TSTAMP(tt_walk)
 			complete = want && !waiting;

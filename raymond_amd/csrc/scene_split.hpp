@@ -44,7 +44,7 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 }
 RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, const uint32_t *lds_masks,
                              WalkScratch &scr, bool walkers, V3 ro, V3 rd, double &closest, int &best, uint32_t &sub, uint32_t debug_flags,
-                             unsigned long long *dbg) {
+                             unsigned long long *dbg, uint32_t cut_lanes = 0u, WalkCarry *carry = nullptr, bool *carried = nullptr, uint32_t cut_round = 0u) {
 	for (uint32_t i = 0; i < n_objects; i++) {
 		const DevObject &o = objs[i];
 		if (o.geometry_kind != 2u) continue; // uniform
@@ -52,7 +52,8 @@ RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_obje
 		bool hit = false;
 		double t = 0.0;
 		uint32_t tri = 0;
-		grid_intersect_wave(g, lds_masks + g.mask_lds_word, scr, walkers, ro, rd, hit, t, tri, debug_flags, dbg);
+		// (walks are only put aside in scenes with ONE grid object — api.cpp: walk_cut — so `carry` holds the state of this object's walk)
+		grid_intersect_wave(g, lds_masks + g.mask_lds_word, scr, walkers, ro, rd, hit, t, tri, debug_flags, dbg, cut_lanes, carry, carried, cut_round);
 		if (walkers && hit && lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = tri;
 	}
 }

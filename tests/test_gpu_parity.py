@@ -853,6 +853,28 @@ def test_role_sorted_trips_with_a_large_object_table(gpu_ctx, oracle, n_spheres)
     assert rel_close(frames[(3, 2)], ref, 1e-9).all(axis=2).mean() >= 0.995
 
 
+def test_walks_put_aside_do_not_change_the_image(gpu_ctx, small_mesh_scene):
+    """Grid scenes: a walk call of a wave stops stepping under its last K rays and leaves their walks — DDA state stored — to the wave's next
+    call (grid_walk.hpp: WalkCarry; RMD_TUNE_WALK_CUT = K + 1).  Every ray takes the same steps and the same tests in the same order whenever it
+    takes them, so every K, with every batch size, in both launch forms, must give the frame of K = 0 (every call finishes every walk)."""
+    st = Settings(scenes.camera(192, 128), sample_count=24, bounce_limit=5, seed=78)
+    cam = st.camera_settings
+    tiles = generate_tiles(192, 128, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, small_mesh_scene)
+    fb = render.Framebuffer(gpu_ctx, 192, 128)
+    frames = {}
+    try:
+        for split, batch, cut in [(1, 0, 1), (1, 0, 0), (1, 0, 3), (1, 0, 9), (1, 0, 32), (3, 0, 1), (3, 0, 0), (3, 0, 2), (3, 0, 5), (3, 0, 17), (3, 16, 7), (3, 64, 13), (0, 0, 0)]:
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), gpu_ctx.set_tunable(abi.RMD_TUNE_WALK_BATCH, batch), gpu_ctx.set_tunable(abi.RMD_TUNE_WALK_CUT, cut)
+            fb.zero()
+            render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+            frames[(split, batch, cut)] = fb.download().tobytes()
+    finally:
+        gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_WALK_BATCH, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_WALK_CUT, 0)
+    assert len(set(frames.values())) == 1
+    fb.close(), ds.close()
+
+
 def test_walk_batching_does_not_change_the_image(gpu_ctx, small_mesh_scene):
     """Grid scenes: a lane whose ray enters a grid's box waits until enough lanes of its wave need a walk (kernels.hip,
     RenderParams::walk_batch).  That is scheduling only — the closest hit is the lexicographic minimum of (distance,

@@ -1,0 +1,9 @@
+set -e
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04_cut
+for k in 0 4 2 8 12; do
+  echo "== RMD_WALK_CUT=$k" | tee -a gpurun_out/r04_cut/sweep.log
+  RMD_WALK_CUT=$k timeout -k 10 120 python tools/quick_time.py C3-end 200 3 2>&1 | tee -a gpurun_out/r04_cut/sweep.log
+  RMD_WALK_CUT=$k timeout -k 10 120 python tools/quick_time.py C3 200 3 2>&1 | tee -a gpurun_out/r04_cut/sweep.log
+done
+timeout -k 10 600 python -m pytest tests/test_gpu_fullsize.py -x -q -k "C3" 2>&1 | tail -5 | tee -a gpurun_out/r04_cut/sweep.log
