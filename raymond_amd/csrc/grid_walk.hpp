@@ -118,6 +118,12 @@ static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 #define RMD_WALK_LOOKAHEAD 16
 #endif
 constexpr uint32_t kWalkLookahead = RMD_WALK_LOOKAHEAD;
+// chunks the owner search (and the load of the triangle indices) runs ahead of the tests: 1 or 2
+#ifndef RMD_WALK_SEARCH_AHEAD
+#define RMD_WALK_SEARCH_AHEAD 2
+#endif
+constexpr uint32_t kWalkSearchAhead = RMD_WALK_SEARCH_AHEAD;
+static_assert(kWalkSearchAhead == 1u || kWalkSearchAhead == 2u, "the search runs one or two chunks ahead");
 
 // Per-wave LDS scratch of the cooperative triangle tests.  A (lane, candidate slot) pair has the key lane * kWalkCand + slot.
 struct alignas(16) WalkScratch {
@@ -594,19 +600,19 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				tri_id = ids[id_index]; // (a lane without a test reads entry 0) — on its way while the current chunk is tested
 				__builtin_amdgcn_wave_barrier(); // every lane has read the markers before the next search rewrites them
 			};
-			uint32_t own = 0, tri_id = 0;
-			search(0u, own, tri_id);
-			for (uint32_t base = 0; base < total; base += 64u) {
+			// One chunk of tests.  (own_x, tri_x): the chunk's owner pairs and triangle indices, searched TWO chunks ago (RMD_WALK_SEARCH_AHEAD = 2) —
+			// the index load has had a whole chunk to arrive — and overwritten here by the search of the chunk two ahead.
+			auto chunk = [&](uint32_t base, uint32_t &own_x, uint32_t &tri_x) {
 				const uint32_t w = base + lane;
 				// every lane loads a record (a lane without a test: some triangle's) and tests it — no zero-filled stand-in, no branch around the loads
-				const uint32_t tri = tri_id;
+				const uint32_t tri = tri_x;
 				const TriRecord r = load_record(recs + (size_t)tri * kTriRecStride);
 				// the owner lane's ray, straight from its registers (every lane takes part in the permute)
-				const int src = (int)((own & 63u) << 2);
+				const int src = (int)((own_x & 63u) << 2);
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
-				const uint32_t own_now = own;
-				if (base + 64u < total) search(base + 64u, own, tri_id);
+				const uint32_t own_now = own_x;
+				if (base + 64u * kWalkSearchAhead < total) search(base + 64u * kWalkSearchAhead, own_x, tri_x);
 				double t = 0.0;
 				const bool h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t) && w < total;
 				RMD_STAMP(5)
@@ -627,6 +633,19 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 						}
 					}
 				}
+			};
+			uint32_t own_a = 0, tri_a = 0;
+			search(0u, own_a, tri_a);
+			if constexpr (kWalkSearchAhead == 2u) { // two register pairs take turns (no copies: a copy would wait for the load it copies)
+				uint32_t own_b = 0, tri_b = 0;
+				if (64u < total) search(64u, own_b, tri_b);
+				for (uint32_t base = 0; base < total; base += 128u) {
+					chunk(base, own_a, tri_a);
+					if (base + 64u >= total) break;
+					chunk(base + 64u, own_b, tri_b);
+				}
+			} else {
+				for (uint32_t base = 0; base < total; base += 64u) chunk(base, own_a, tri_a);
 			}
 			RMD_STAMP(6)
 			__builtin_amdgcn_wave_barrier(); // the scratch is rewritten next round

@@ -38,7 +38,7 @@ constexpr size_t kMaskBudgetBytes = 48u * 1024u;
 // doubles per entry of the per-sample scratch of split launches: r, g, b and one of padding = one 32-byte sector
 constexpr uint32_t kSampleStride = 4;
 // walk batching (kernels.hip): lanes of a wave that must be waiting for a grid walk before one is run
-constexpr uint32_t kWalkBatchDefault = 40;
+constexpr uint32_t kWalkBatchDefault = 32;
 // walks put aside (grid_walk.hpp: cut_lanes): a walk call leaves its last K walkers to the wave's next call
 constexpr uint32_t kWalkCutDefault = 4;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
@@ -51,6 +51,10 @@ constexpr double kMaxRoughness = 512.0;
 constexpr uint32_t kGridWavesPerWg = RMD_GRID_WAVES;
 // waves of a persistent workgroup (one per CU: all 16 wave slots that 128 registers per lane leave)
 constexpr uint32_t kPersistWavesPerWg = 16;
+#ifndef RMD_GRID_PERSIST_WAVES
+#define RMD_GRID_PERSIST_WAVES 16
+#endif
+constexpr uint32_t kGridPersistWavesPerWg = RMD_GRID_PERSIST_WAVES; // ... of the grid instantiation
 // the spheres kernel's split launches (render_kernel.hpp: render_wave_sorted): path slots of a wave's pool and waves of a persistent workgroup —
 // 16 pools of 112 slots (86 bytes each) and the object table fit the CU's 160 KB
 #ifndef RMD_SORT_SLOTS

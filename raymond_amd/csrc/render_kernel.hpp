@@ -72,7 +72,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	return best;
 }
 
-// A walk is run when RenderParams::walk_batch lanes of the wave wait for one (launch.hpp: kWalkBatchDefault = 40; with the persistent
+// A walk is run when RenderParams::walk_batch lanes of the wave wait for one (launch.hpp: kWalkBatchDefault = 32; with the persistent
 // workgroups 40 / 24 / 6 / look-ahead 16 measured 1.7 % faster on the benchmark mesh than round 1's 32 / 16 / 4 / 12),
 // ... or fewer than this many lanes could do anything else on this trip (a trip costs the same for 5 lanes as for 50)
 #ifndef RMD_WALK_MIN_RUNNABLE
@@ -730,7 +730,7 @@ constexpr bool kSortedTrips = RMD_SORTED_TRIPS && MODE == kModeTilesBuffered && 
 template <int MODE, bool GRID>
 __host__ __device__ inline size_t wave_lds_of(uint32_t n_grids) { return kSortedTrips<MODE, GRID> ? sizeof(SortPool) : wave_lds_bytes(n_grids); }
 template <int MODE, bool GRID>
-constexpr uint32_t kPersistWaves = kSortedTrips<MODE, GRID> ? kSortedWavesPerWg : kPersistWavesPerWg;
+constexpr uint32_t kPersistWaves = kSortedTrips<MODE, GRID> ? kSortedWavesPerWg : GRID ? kGridPersistWavesPerWg : kPersistWavesPerWg;
 template <int MODE, bool GRID, bool PERSIST>
 __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ? 64 * kGridWavesPerWg : 64,
                              GRID ? RMD_GRID_MINW : (kSortedTrips<MODE, GRID>) ? (RMD_SORT_WAVES * RMD_SORT_WGS_PER_CU / 4) : (PERSIST ? 4 : RMD_NOGRID_MINW)) void render_kernel(
