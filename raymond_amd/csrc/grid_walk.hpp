@@ -367,6 +367,9 @@ RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bi
 // walk goes on from that state beside the new rays.  The steps, candidates and tests of every ray are those of an uninterrupted walk, in the
 // same order: the result is the same.  The caller passes K > 0 only for calls with many more than K walkers (every call then advances every
 // walker by at least a step) and K = 0 when the wave has nothing else to do, which finishes every walk.
+// DEEP: the form of the split launches' kernel — walks may be put aside, and the chunk loop's owner search runs two chunks ahead; the plain form
+// (direct mode: launches of a few samples per pixel; the probes) finishes every walk and searches one chunk ahead, in 10 fewer registers.
+template <bool DEEP = false>
 RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, WalkScratch &scr, bool want, V3 ro, V3 rd, bool &hit_out,
                                  double &t_out, uint32_t &tri_out, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr, uint32_t cut_lanes = 0u,
                                  WalkCarry *carry = nullptr, bool *carried = nullptr, uint32_t cut_round = 0u) {
@@ -449,6 +452,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		}
 	}
 
+	if constexpr (!DEEP) cut_lanes = 0u, cut_round = 0u, carry = nullptr, carried = nullptr;
 	if (carried) {
 		if (*carried && walking) { // the walk goes on where the previous call left it
 			tmx = carry->tm[0][lane], tmy = carry->tm[1][lane], tmz = carry->tm[2][lane];
@@ -602,6 +606,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			};
 			// One chunk of tests.  (own_x, tri_x): the chunk's owner pairs and triangle indices, searched TWO chunks ago (RMD_WALK_SEARCH_AHEAD = 2) —
 			// the index load has had a whole chunk to arrive — and overwritten here by the search of the chunk two ahead.
+			constexpr uint32_t ahead = DEEP ? kWalkSearchAhead : 1u;
 			auto chunk = [&](uint32_t base, uint32_t &own_x, uint32_t &tri_x) {
 				const uint32_t w = base + lane;
 				// every lane loads a record (a lane without a test: some triangle's) and tests it — no zero-filled stand-in, no branch around the loads
@@ -612,7 +617,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				const uint32_t own_now = own_x;
-				if (base + 64u * kWalkSearchAhead < total) search(base + 64u * kWalkSearchAhead, own_x, tri_x);
+				if (base + 64u * ahead < total) search(base + 64u * ahead, own_x, tri_x);
 				double t = 0.0;
 				const bool h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t) && w < total;
 				RMD_STAMP(5)
@@ -636,7 +641,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			};
 			uint32_t own_a = 0, tri_a = 0;
 			search(0u, own_a, tri_a);
-			if constexpr (kWalkSearchAhead == 2u) { // two register pairs take turns (no copies: a copy would wait for the load it copies)
+			if constexpr (ahead == 2u) { // two register pairs take turns (no copies: a copy would wait for the load it copies)
 				uint32_t own_b = 0, tri_b = 0;
 				if (64u < total) search(64u, own_b, tri_b);
 				for (uint32_t base = 0; base < total; base += 128u) {

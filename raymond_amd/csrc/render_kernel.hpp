@@ -505,12 +505,17 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			if (wm != 0ull && ((uint32_t)__popcll(wm) >= Pt.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
 				trips_since_walk = 0;
 				// walks are put aside only by a call with many walkers in a wave that has other lanes to run: otherwise every walk is finished
-				const uint32_t n_walkers = (uint32_t)__popcll(wm);
-				const bool cut = n_walkers >= kWalkCutMinWalkers && (uint32_t)__popcll(rm) >= kWalkCutMinRunnable;
-				const uint32_t cut_lanes = cut ? Pt.walk_cut & 0xffu : 0u, cut_round = cut ? (Pt.walk_cut >> 8) & 0xffu : 0u;
-				intersect_grids(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters,
-				                cut_lanes, carry, &carried, cut_round);
-				waiting = carried;
+				if constexpr (MODE != kModeTiles) {
+					const uint32_t n_walkers = (uint32_t)__popcll(wm);
+					const bool cut = n_walkers >= kWalkCutMinWalkers && (uint32_t)__popcll(rm) >= kWalkCutMinRunnable;
+					const uint32_t cut_lanes = cut ? Pt.walk_cut & 0xffu : 0u, cut_round = cut ? (Pt.walk_cut >> 8) & 0xffu : 0u;
+					intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters,
+					                      cut_lanes, carry, &carried, cut_round);
+					waiting = carried;
+				} else { // direct mode (launches of a few samples per pixel): every call finishes its walks — the carry's registers are not worth it there
+					intersect_grids<false>(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters);
+					waiting = false;
+				}
 			}
 			RMD_TSTAMP(tt_walk)
 			complete = want && !waiting;

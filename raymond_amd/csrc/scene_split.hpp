@@ -42,6 +42,7 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 	}
 	return enters;
 }
+template <bool DEEP = false>
 RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, const uint32_t *lds_masks,
                              WalkScratch &scr, bool walkers, V3 ro, V3 rd, double &closest, int &best, uint32_t &sub, uint32_t debug_flags,
                              unsigned long long *dbg, uint32_t cut_lanes = 0u, WalkCarry *carry = nullptr, bool *carried = nullptr, uint32_t cut_round = 0u) {
@@ -53,7 +54,7 @@ RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_obje
 		double t = 0.0;
 		uint32_t tri = 0;
 		// (walks are only put aside in scenes with ONE grid object — api.cpp: walk_cut — so `carry` holds the state of this object's walk)
-		grid_intersect_wave(g, lds_masks + g.mask_lds_word, scr, walkers, ro, rd, hit, t, tri, debug_flags, dbg, cut_lanes, carry, carried, cut_round);
+		grid_intersect_wave<DEEP>(g, lds_masks + g.mask_lds_word, scr, walkers, ro, rd, hit, t, tri, debug_flags, dbg, cut_lanes, carry, carried, cut_round);
 		if (walkers && hit && lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = tri;
 	}
 }
