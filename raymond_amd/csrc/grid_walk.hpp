@@ -620,7 +620,9 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				if (base + 64u * ahead < total) search(base + 64u * ahead, own_x, tri_x);
 				double t = 0.0;
 				const bool h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t) && w < total;
+#if !defined(RMD_STAMP_OUTER_ONLY)
 				RMD_STAMP(5)
+#endif
 				unsigned long long hits = __ballot(h);
 				while (hits) {
 					const int l = (int)__builtin_ctzll(hits);
