@@ -1020,3 +1020,42 @@ def test_launch_forms_of_grid_scenes_are_bit_identical(gpu_ctx, small_mesh_scene
         if st.bounce_limit:
             assert (out[(0, 0)] != base).any()
         fb.close(), ds.close()
+
+
+# ------------------------------------------------------------------ the HIP path against the SECOND reading of the reference source
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["spheres", "mesh", "mesh-thin-lens"])
+def test_per_sample_against_the_second_reading_of_the_source(gpu_ctx, small_mesh_scene, what):
+    """tests/second_reading.py restates the whole path a second time, in plain Python floats, from the Rust text alone (it shares no code with
+    oracle/oracle.cpp; tests/test_second_reading.py holds the oracle against it bit for bit).  Here the HIP kernel itself is held against it,
+    sample by sample — vertex sequence (object and triangle at every depth) and radiance to the stated 1e-9 — without the C++ oracle in between."""
+    import second_reading as sr
+    from test_second_reading import second_reading_scene
+
+    if what == "spheres":
+        scene, st, n = scenes.reflective_spheres(), scenes.config_settings("C2"), 20000
+    else:
+        lens = what == "mesh-thin-lens"
+        scene = small_mesh_scene
+        st = Settings(scenes.camera(480, 270, aperture_radius=0.5 if lens else 0.0), sample_count=1, bounce_limit=5, seed=scenes.SEED + 11, use_dof=lens)
+        n = 12000
+    cam = st.camera_settings
+    rng = np.random.default_rng(41)
+    xy = np.stack([rng.integers(0, cam.backbuffer_width, n), rng.integers(0, cam.backbuffer_height, n)], axis=1).astype(np.uint32)
+    smp = rng.integers(0, 4000, n).astype(np.uint32)
+    ds = render.DeviceScene(gpu_ctx, scene)
+    drgb, dpo, dps = probe.trace_samples(gpu_ctx, ds, cam, st, xy, smp, paths=True)
+    ds.close()
+    sc, c = second_reading_scene(scene, cam)
+    same_path, close, lit, through_mesh = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool), 0, 0
+    for i in range(n):
+        path = []
+        rgb = sr.sample_pixel(sc, c, {"bounce_limit": st.bounce_limit}, st.seed, int(xy[i, 0]), int(xy[i, 1]), int(smp[i]), use_dof=st.use_dof, path=path)
+        k = len(path)
+        same_path[i] = dpo[i, :k].tolist() == [p[0] for p in path] and dps[i, :k].tolist() == [p[1] for p in path] and (dpo[i, k:] == -2).all()
+        close[i] = rel_close(drgb[i], np.asarray(rgb), 1e-9).all()
+        lit += any(v != 0.0 for v in rgb)
+        through_mesh += any(p[0] == 1 for p in path)
+    assert close[same_path].all(), "a sample with the second reading's exact vertex sequence differs beyond 1e-9"
+    assert same_path.mean() >= 0.999 and close.mean() >= 0.999
+    assert lit > n // 20 and (what == "spheres" or through_mesh > n // 20)
