@@ -119,6 +119,10 @@ static_assert(kWalkCand >= 1 && kWalkCand <= 8, "1..8 candidates per round");
 #endif
 constexpr uint32_t kWalkLookahead = RMD_WALK_LOOKAHEAD;
 // chunks the owner search (and the load of the triangle indices) runs ahead of the tests: 1 or 2
+#ifndef RMD_WALK_STEP_PRIO
+#define RMD_WALK_STEP_PRIO 2 // s_setprio level of a round's stepping loop (0 = not raised)
+#endif
+constexpr int kWalkStepPrio = RMD_WALK_STEP_PRIO;
 #ifndef RMD_WALK_SEARCH_AHEAD
 #define RMD_WALK_SEARCH_AHEAD 2
 #endif
@@ -492,6 +496,9 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		// `budget` = steps this lane may still take in this round: unlimited until its first candidate, kWalkLookahead
 		// after it, 0 once kWalkCand candidates are recorded.
 		uint32_t n_cand = 0;
+		// the stepping loop is a chain of dependent LDS reads and branches run by a quarter of the wave's lanes: at a raised priority it is through sooner, and
+		// what it yields the SIMD's other waves — their trips are dense vector code — take up (RMD_WALK_STEP_PRIO: measured −1.4 %)
+		if constexpr (kWalkStepPrio != 0) __builtin_amdgcn_s_setprio(kWalkStepPrio);
 		if (count_events && lane == 0) atomicAdd(&dbg[3], 1ull);
 		// LEAN (uniform per round): the mask has one bit per cell and every cell inside the grid has an index inside the cell
 		// array (res.z <= res.y), so neither the shift nor the index test is needed as long as no lane of the wave started
@@ -514,6 +521,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		if (lean) dda_collect_candidates<true>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, cut_lanes);
 #endif
 		else dda_collect_candidates<false>(lds_mask, mask_shift, mask_pad_bit, idx_limit, scr, lane, walking, n_cand, idx, prev, remx, remy, remz, tmx, tmy, tmz, tdx, tdy, tdz, dix, diy, diz, cut_lanes, count_events ? dbg : nullptr);
+		if constexpr (kWalkStepPrio != 0) __builtin_amdgcn_s_setprio(0);
 		RMD_STAMP(1)
 		if (cut_lanes != 0u && walking && n_cand == 0u) put_aside(); // the stepping was cut short under a lane that has found nothing to test yet
 		if (__ballot(n_cand != 0u) == 0ull) {
