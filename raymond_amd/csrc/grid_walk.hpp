@@ -344,7 +344,7 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 	    : "vcc", "scc", "memory", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98");
 // LEAN (uniform per round): the mask holds a bit for every cell of the array, every cell inside the grid has an index inside the array
 // (res.z <= res.y) and no lane of the wave started from a cell outside the grid (Q6): the index then needs neither the clamp to the mask's zero
-// word nor the test against the end of the array — 19 + 13 instructions per step for 20 + 15.
+// word nor the test against the end of the array — 19 + 15 instructions per step for 20 + 17 (two of the scalar ones count the lanes still stepping: cut_lanes).
 template <bool LEAN>
 RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bit, uint32_t idx_limit, uint32_t cand_base, bool &walking, uint32_t &n_cand,
                                              uint32_t &idx, uint32_t &prev, uint32_t &remx, uint32_t &remy, uint32_t &remz, double &tmx, double &tmy, double &tmz,

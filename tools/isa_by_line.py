@@ -9,6 +9,8 @@ import collections, os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pat = re.compile(sys.argv[1])
 extra = sys.argv[2:]
+# RMD_ISA_CLASS=moves: count only moves, selects and compares (v_mov*, v_cndmask*, v_cmp*, v_readlane / v_writelane), one each
+only_moves = os.environ.get("RMD_ISA_CLASS") == "moves"
 out = "/tmp/isa_by_line.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-DRMD_DIAG=0", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                 "-gline-tables-only", "-I/opt/rocm/include", "-S", "--cuda-device-only", "-o", out, os.path.join(root, "raymond_amd/csrc/kernels.hip")] + extra,
@@ -38,6 +40,11 @@ for line in open(out):
         continue
     m = re.match(r"\s+(v_\w+)", line)
     if m and cur:
+        if only_moves:
+            if not m.group(1).startswith(("v_mov", "v_cndmask", "v_cmp", "v_readlane", "v_writelane", "v_accvgpr")): continue
+            cost[cur] += 1.0
+            count[cur] += 1
+            continue
         cost[cur] += weight(m.group(1))
         count[cur] += 1
 total = sum(cost.values())
