@@ -1,5 +1,6 @@
-"""The full C3 frame in every launch form (0 = persistent workgroups, 1 = one wave per work item) and several splits, N frames each: every
-frame must equal the first one bit for bit (work items are drawn in a different order on every run).  python tools/stress_modes.py [frames] [spp]"""
+"""The full C3 frame in every launch form (0 = persistent workgroups, 1 = one wave per work item), several splits and several values of the walk cut
+(RMD_TUNE_WALK_CUT: 0 = the library's K, 1 = every walk call finishes its walks, 9 = K 8), N frames each: every frame must equal the first one bit
+for bit (work items are drawn in a different order on every run, and with them which walks are put aside when).  python tools/stress_modes.py [frames] [spp]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raymond_amd import abi, render, scenes
@@ -17,7 +18,8 @@ with render.Context(0) as ctx:
     want, bad = None, 0
     for mode in (0, 1):
         for split in (0, 2, 7):
-            ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, mode), ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
+          for cut in (0, 1, 9):
+            ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, mode), ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), ctx.set_tunable(abi.RMD_TUNE_WALK_CUT, cut)
             for i in range(frames):
                 fb.zero()
                 render.render_tiles(ctx, ds, cam, st, tiles, fb)
@@ -26,7 +28,7 @@ with render.Context(0) as ctx:
                     want = got
                 elif got != want:
                     bad += 1
-                    print("MISMATCH mode", mode, "split", split, "frame", i, flush=True)
-            print("mode %d split %d: %d frames, %d mismatches so far" % (mode, split, frames, bad), flush=True)
+                    print("MISMATCH mode", mode, "split", split, "cut", cut, "frame", i, flush=True)
+            print("mode %d split %d cut %d: %d frames, %d mismatches so far" % (mode, split, cut, frames, bad), flush=True)
     print("stress: %s" % ("FAILED" if bad else "ok"))
     sys.exit(1 if bad else 0)
