@@ -473,3 +473,22 @@ def sample_pixel(scene, cam, settings, seed, x, y, sample, use_dof=False, path=N
     except Panic:
         return (0.0, 0.0, 0.0)
     return trace(scene, settings, stream, origin, direction, 1, path)
+
+
+# ================================================================ the output stage (cli_old/src/main.rs:161-181, after TaskHandle::await's division, src/trace.rs:95)
+def resolve_pixel(accum_rgb, sample_count, exposure=1.0, gamma=2.2):
+    """-> (r, g, b) as the 8-bit values the reference writes: 1 - exp(-p * exposure), powf(1 / gamma), * 255, Vector3::cast::<u8>() — None (the
+    pixel keeps its initial (0, 0, 0)) when ANY component is NaN or outside (-1, 256); the cast truncates toward zero."""
+    out = []
+    for a in accum_rgb:
+        p = div(a, sample_count)
+        try:
+            e = math.exp(p * -1.0 * exposure)
+        except OverflowError:
+            e = float("inf")
+        tm = 1.0 - e
+        tm = powf(tm, div(1.0, gamma))
+        out.append(tm * 255.0)
+    if any(v != v or not (-1.0 < v < 256.0) for v in out):
+        return (0, 0, 0)
+    return tuple(int(v) for v in out)

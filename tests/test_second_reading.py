@@ -218,3 +218,24 @@ def test_second_reading_philox_known_answers():
     assert sr.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
     assert sr.philox4x32_10((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF)) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
     assert sr.philox4x32_10((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+
+
+def test_oracle_output_stage_equals_a_second_reading_of_the_source(oracle):
+    """cli_old/src/main.rs:161-181 (tone map, gamma, the Vector3 cast to u8 that fails as a whole) byte for byte, incl. negative, huge, infinite and NaN sums."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    acc = rng.exponential(40.0, (n, 3))
+    acc[:200] *= 1e-6
+    acc[200:400] *= 1e3
+    acc[400:420, 1] = np.nan
+    acc[420:440, 0] = np.inf
+    acc[440:460, 2] = -np.inf
+    acc[460:520] *= -1.0  # negative radiance: 1 - exp(+x) < 0, powf of a negative base is NaN -> the whole pixel stays black
+    acc[520:540] = 0.0
+    acc[540:560, 0] = -1e-300
+    spp = 64
+    got = oracle.resolve_tonemap(acc, spp)
+    for i in range(n):
+        want = sr.resolve_pixel(tuple(map(float, acc[i])), float(spp))
+        assert tuple(int(v) for v in got[i]) == want, (i, acc[i], got[i], want)
+    assert (got > 0).any(axis=1).mean() > 0.8 and (got[400:420] == 0).all() and (got[440:520] == 0).all() and (got[420:440, 0] == 255).all()
