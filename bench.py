@@ -306,11 +306,16 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-            # HIP events recorded by the library around the kernel, on the stream it was launched on
-            kernel_ms.append(ctx.last_kernel_ms())
+            # HIP events recorded by the library around the kernel, on the stream it was launched on.  Reading them waits for the kernel: at N = 1,
+            # where the roofline needs every launch's duration, the steps are host-synchronous; with several ranks the steps are queued back to back
+            # (zeroing, kernel, collective — all on one stream) and only the last launch's duration is read, after the timed region
+            if world == 1:
+                kernel_ms.append(ctx.last_kernel_ms())
         torch.cuda.synchronize(dev)
         barrier()
         elapsed = time.perf_counter() - t0
+        if world > 1:
+            kernel_ms.append(ctx.last_kernel_ms())
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
