@@ -22,7 +22,12 @@
  * Conventions: plain C, POD structs, caller owns every buffer it passes, the
  * library owns the opaque handles.  Every function returns rmd_status
  * (0 = OK); nothing throws or aborts across the boundary (the reference's
- * failure mode is a Rust panic; here it is a status + rmd_last_error()).
+ * failure mode is a Rust panic — and a hang: `TaskHandle::await` polls a counter
+ * that a panicked worker never decrements, src/trace.rs:82-92; here it is a
+ * status + rmd_last_error()).  That holds inside the kernel too: every loop of
+ * the render kernel has a bound that no input reaches, and a wave that runs
+ * into one sets a device fault word, stops the launch handing out work and
+ * leaves; the host then returns RMD_ERR_DEVICE_FAULT instead of a frame.
  * A context is thread-compatible (one calling thread at a time per handle).
  * All arithmetic is IEEE binary64, as in the reference (core/src/math.rs:10).
  */
@@ -36,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RMD_ABI_VERSION 3u
+#define RMD_ABI_VERSION 4u
 
 typedef int32_t rmd_status;
 enum {
@@ -47,7 +52,11 @@ enum {
 	RMD_ERR_OUT_OF_MEMORY = 4,
 	RMD_ERR_GRID_INDEX = 5,       /* grid build hit the reference's out-of-bounds panic (Q5) */
 	RMD_ERR_UNSUPPORTED = 6,      /* e.g. bounce_limit above RMD_MAX_BOUNCE_LIMIT            */
-	RMD_ERR_RCCL = 7
+	RMD_ERR_RCCL = 7,
+	RMD_ERR_DEVICE_FAULT = 8      /* a loop of the render kernel ran past its bound (it cannot, for any input: an internal fault);
+	                                 the launch was cut short, the frame it wrote to is NOT valid; text in rmd_last_error.
+	                                 Reported by the first call that waits for the launch (rmd_render_tiles,
+	                                 rmd_context_synchronize, rmd_last_kernel_ms, rmd_framebuffer_download, rmd_reduce_framebuffer) */
 };
 
 /* ---- scene description (mirrors core/src/scene.rs:8-45, core/src/lib.rs:21-26) ---- */
@@ -173,7 +182,9 @@ typedef struct rmd_tile_rect {
  *                           hit's lobe known when the hit is: a diffuse bounce off a black surface can end its path (see
  *                           RMD_RENDER_END_BLACK_PATHS) without the depth's block ever being drawn.  (Since ABI 2; ABI 1 took r from
  *                           the depth's own block: same distribution, different samples.  ABI 3 changed no sample, only which
- *                           rmd_settings.flags value ends black paths in scenes with grids.)
+ *                           rmd_settings.flags value ends black paths in scenes with grids; ABI 4 changed no sample either: it added
+ *                           RMD_ERR_DEVICE_FAULT, rmd_reduce_framebuffer_async, rmd_launch_info.waves_per_workgroup and the rule for
+ *                           non-finite scene parameters below.)
  * (One Philox evaluation per path segment, and no RNG state beyond a block counter and those 22 bits.)
  */
 
@@ -256,10 +267,13 @@ rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms);
 typedef struct rmd_launch_info {
 	uint32_t passes;          /* launches of the render kernel (the per-sample scratch may force several)                           */
 	uint32_t split_k;         /* work items per wave tile of the last pass; > 1 = pooled (pixel, sample) hand-out + ordered sum    */
-	uint32_t persistent;      /* 1 = persistent workgroups drawing work items from a counter, 0 = one wave per work item           */
+	uint32_t persistent;      /* 1 = persistent workgroups drawing work items from a counter, 0 = one wave per work item — the form
+	                             the last pass was actually LAUNCHED in (a scene whose object table and masks leave a persistent
+	                             workgroup too little LDS runs as one wave per item whatever was asked for)                       */
 	uint32_t end_black_paths; /* 1 = zero-throughput paths were ended (see RMD_RENDER_END_BLACK_PATHS)                             */
 	uint32_t has_grid;        /* 1 = the grid instantiation (wave-cooperative DDA walk) ran                                         */
-	uint32_t _pad[3];
+	uint32_t waves_per_workgroup; /* waves of a workgroup of the last pass (persistent form: 16 unless the LDS left room for fewer) */
+	uint32_t _pad[2];
 } rmd_launch_info;
 rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out);
 
@@ -274,8 +288,11 @@ rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32
 #define RMD_COMM_ID_BYTES 128
 /* One process per GPU.  rank 0 calls rmd_comm_unique_id and ships the 128 bytes to the other ranks by any means.
  * Environment: RCCL shares buffers between the ranks through HIP IPC; on hosts whose driver supports dmabuf IPC only, every rank needs
- * HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment BEFORE its first HIP call.  The library sets it (without overwriting a value the caller
- * chose) when it is loaded; a process that has already made HIP calls by then must export it itself. */
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment BEFORE its first HIP call (the HSA runtime reads its environment once).  The library never
+ * changes the environment on its own: a multi-GPU caller either exports the variable or calls rmd_comm_prepare_process() — which sets it to 0
+ * unless the environment already holds a value — before rmd_context_create and any other HIP call of the process; single-GPU callers are not
+ * affected.  rmd_comm_create names the variable in its error text when RCCL's initialisation fails without it. */
+rmd_status rmd_comm_prepare_process(void);
 rmd_status rmd_comm_unique_id(uint8_t id_out[RMD_COMM_ID_BYTES]);
 rmd_status rmd_comm_create(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES], int32_t rank, int32_t world_size,
                            rmd_comm **out);
@@ -283,6 +300,9 @@ void rmd_comm_destroy(rmd_comm *comm);
 /* In-place ncclReduce(sum, f64) of the accumulated framebuffer to `root` over xGMI.
  * Every pixel is non-zero on exactly one rank, so the sum is bit-identical to a 1-GPU render. */
 rmd_status rmd_reduce_framebuffer(rmd_comm *comm, double *accum_dev, size_t n_doubles, int32_t root);
+/* Same, enqueue only (on the context's stream, behind the renders enqueued before it); pair with rmd_context_synchronize.  Lets a rank queue
+ * zeroing, rmd_render_tiles_async and the reduce of several frames back to back. */
+rmd_status rmd_reduce_framebuffer_async(rmd_comm *comm, double *accum_dev, size_t n_doubles, int32_t root);
 
 /* ---- host-side grid build (AccGrid::build_from_mesh, core/src/geometry/acc_grid.rs:6-83) ---- */
 typedef struct rmd_grid_build rmd_grid_build; /* owns the arrays a rmd_grid_desc points at */

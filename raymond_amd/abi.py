@@ -7,7 +7,7 @@ compiled library.
 """
 import ctypes as C
 
-RMD_ABI_VERSION = 3
+RMD_ABI_VERSION = 4
 
 RMD_OK = 0
 RMD_ERR_INVALID_ARGUMENT = 1
@@ -17,6 +17,7 @@ RMD_ERR_OUT_OF_MEMORY = 4
 RMD_ERR_GRID_INDEX = 5
 RMD_ERR_UNSUPPORTED = 6
 RMD_ERR_RCCL = 7
+RMD_ERR_DEVICE_FAULT = 8
 
 STATUS_NAMES = {
     0: "RMD_OK",
@@ -27,6 +28,7 @@ STATUS_NAMES = {
     5: "RMD_ERR_GRID_INDEX",
     6: "RMD_ERR_UNSUPPORTED",
     7: "RMD_ERR_RCCL",
+    8: "RMD_ERR_DEVICE_FAULT",
 }
 
 # enum Geometry { Plane, Sphere, Grid } — core/src/scene.rs:9-13
@@ -118,5 +120,6 @@ class LaunchInfo(C.Structure):  # rmd_launch_info
         ("persistent", C.c_uint32),
         ("end_black_paths", C.c_uint32),
         ("has_grid", C.c_uint32),
-        ("_pad", C.c_uint32 * 3),
+        ("waves_per_workgroup", C.c_uint32),
+        ("_pad", C.c_uint32 * 2),
     ]

@@ -77,6 +77,21 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		rmd_context_destroy(ctx);
 		return rmd::fail(nullptr, RMD_ERR_HIP, "hipEventCreate failed");
 	}
+	// the fault words: pinned host memory the device writes through (coherent: visible to the host once the launch has completed)
+	{
+		void *h = nullptr, *d = nullptr;
+		hipError_t fe = hipHostMalloc(&h, rmd::kFaultWords * sizeof(uint32_t), hipHostMallocMapped);
+		if (fe == hipSuccess) {
+			ctx->h_fault = (uint32_t *)h;
+			std::memset(h, 0, rmd::kFaultWords * sizeof(uint32_t));
+			fe = hipHostGetDevicePointer(&d, h, 0);
+		}
+		if (fe != hipSuccess) {
+			rmd_context_destroy(ctx);
+			return rmd::fail(nullptr, RMD_ERR_HIP, std::string("fault words (hipHostMalloc): ") + hipGetErrorString(fe));
+		}
+		ctx->d_fault = (uint32_t *)d;
+	}
 	*out = ctx;
 	return RMD_OK;
 }
@@ -130,7 +145,7 @@ rmd_status check_render_args(rmd_context *ctx, const rmd_scene *scene, const rmd
 	if (st->flags & ~(RMD_RENDER_DOF | RMD_RENDER_TRACE_BLACK_PATHS | RMD_RENDER_END_BLACK_PATHS)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: unknown bits in rmd_settings.flags");
 	if ((st->flags & RMD_RENDER_TRACE_BLACK_PATHS) && (st->flags & RMD_RENDER_END_BLACK_PATHS))
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "render: RMD_RENDER_TRACE_BLACK_PATHS and RMD_RENDER_END_BLACK_PATHS exclude each other");
-	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, 1) + (scene->n_grids == 0u ? rmd::kSortPoolBytes : 0u) > rmd::kLdsBudgetBytes)
+	if (rmd::render_lds_bytes(scene->n_objects, scene->mask_words_total, 1) + (scene->n_grids == 0u ? rmd::kSortPoolBytes : 0u) > rmd::kLdsBudgetBytes) // (one wave's area, head included)
 		return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "render: object table + grid masks exceed the 160 KiB LDS of a CU");
 	return RMD_OK;
 }
@@ -143,6 +158,29 @@ rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text) {
 	if (ctx) ctx->last_error = text;
 	tl_last_error = text;
 	return status;
+}
+
+static_assert(RMD_MAX_BOUNCE_LIMIT_DEV == RMD_MAX_BOUNCE_LIMIT, "launch.hpp mirrors include/raymond_hip.h");
+
+// Called after every wait for the context's stream.  The words are host memory: two loads when nothing happened.
+rmd_status check_fault(rmd_context *ctx) {
+	if (!ctx || !ctx->h_fault) return RMD_OK;
+	volatile uint32_t *f = ctx->h_fault;
+	const uint32_t code = f[0];
+	if (code == 0u) return RMD_OK;
+	const uint32_t item = f[1], reports = f[2];
+	f[0] = 0u, f[1] = 0u, f[2] = 0u; // the next launch starts clean
+	std::string what;
+	if (code & kFaultTripLoop) what += " trip loop of render_wave;";
+	if (code & kFaultSortedTripLoop) what += " trip loop of render_wave_sorted;";
+	if (code & kFaultWorkLoop) what += " work loop of a persistent workgroup;";
+	if (code & kFaultWalkRounds) what += " round loop of a grid walk;";
+	if (code & ~(kFaultTripLoop | kFaultSortedTripLoop | kFaultWorkLoop | kFaultWalkRounds)) what += " unknown code;";
+	char num[96];
+	std::snprintf(num, sizeof(num), " %u wave(s) reported, the last one at work item %u (code 0x%x)", reports, item, code);
+	return fail(ctx, RMD_ERR_DEVICE_FAULT,
+	            "device fault: a loop of the render kernel ran past its bound —" + what + num +
+	                "; the launch was cut short and the framebuffer it wrote to is not valid");
 }
 
 // generate_primary_ray's loop-invariant terms (src/trace.rs:323-330), evaluated with the host libm
@@ -168,7 +206,11 @@ RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const r
 	P.use_dof = ((st->flags & RMD_RENDER_DOF) && cam->aperture_radius > 0.0) ? 1u : 0u; // off by default, as in the reference's loop (:199)
 	// flags 0 = reference-identical: zero-throughput paths are ended only where that provably changes no sample — a scene without grids
 	// (its one NaN source, the interpolated normal of a mesh hit, does not exist there); END opts in for scenes with grids, TRACE never ends
-	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : ((st->flags & RMD_RENDER_END_BLACK_PATHS) || !scene || scene->n_grids == 0u) ? 1u : 0u;
+	// — AND whose parameters are all inside the class for which that is proved (rmd_scene::regular: an Emission of (inf, 0, 0), a NaN colour, a
+	// material of roughness 0 or a sphere of radius 0 make non-finite radiance reachable without a mesh; such a scene is traced like one with a grid)
+	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : ((st->flags & RMD_RENDER_END_BLACK_PATHS) || !scene || (scene->n_grids == 0u && scene->regular)) ? 1u : 0u;
+	P.shade_last_depth = (scene && !scene->regular) ? 1u : 0u;
+	P.fault = ctx ? ctx->d_fault : nullptr;
 	P.walk_batch = rmd::kWalkBatchDefault;
 	if (ctx && ctx->tunable[RMD_TUNE_WALK_BATCH] > 0) P.walk_batch = (uint32_t)ctx->tunable[RMD_TUNE_WALK_BATCH]; // any value gives the same image
 	// walks put aside for the wave's next walk call (grid_walk.hpp): the carried state is ONE walk's, so only in scenes with one grid object.
@@ -205,6 +247,7 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->d_debug_counters) (void)hipFree(ctx->d_debug_counters);
 	if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
 	if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
+	if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -213,12 +256,15 @@ void rmd_context_destroy(rmd_context *ctx) {
 
 const char *rmd_last_error(const rmd_context *ctx) { return ctx ? ctx->last_error.c_str() : tl_last_error.c_str(); }
 
-rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_t n_objects, const rmd_grid_desc *grids, uint32_t n_grids,
-                            rmd_scene **out) {
+// (`sc`: the scene under construction, owned by the caller's frame so that an exception — std::bad_alloc from one of the host-side tables: a
+// 256^3 grid needs a gigabyte for its cell entries alone — can still release what has been uploaded)
+static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects, uint32_t n_objects, const rmd_grid_desc *grids, uint32_t n_grids,
+                                    rmd_scene **out, rmd_scene *&sc) {
 	if (rmd_status s = bind(ctx)) return s;
 	if (!out || (n_objects && !objects) || (n_grids && !grids)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: null argument");
 	*out = nullptr;
 	std::vector<rmd::DevObject> hobj(n_objects);
+	bool regular = true;
 	for (uint32_t i = 0; i < n_objects; i++) {
 		const rmd_object &o = objects[i];
 		rmd::DevObject &d = hobj[i];
@@ -232,8 +278,29 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		// the GGX angle roughness^2 * sqrt(u / (1 - u)) must stay inside sincos_cw's reduction range (device_core.hpp)
 		if (o.material.kind != RMD_MAT_EMISSION && std::fabs(o.material.roughness) > rmd::kMaxRoughness)
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: |roughness| > 512 is not supported");
+		// (the bounce weight is formed as ONE quotient whose denominator holds (roughness^2 / 8)^2 for a surface seen from behind: it must not underflow)
+		if (o.material.kind != RMD_MAT_EMISSION && o.material.roughness != 0.0 && std::fabs(o.material.roughness) < rmd::kMinRoughness)
+			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: 0 < |roughness| < 1e-12 is not supported");
 		d.roughness = o.material.roughness;
 		d.metalness = o.material.kind == RMD_MAT_METAL ? 1.0 : 0.0; // src/trace.rs:248-249
+		// Is this object inside the class of parameters for which "a path whose throughput is exactly (0, 0, 0) contributes exactly (0, 0, 0)" is
+		// proved?  The proof needs every later vertex of such a path to have a FINITE radiance (0 x NaN = NaN, src/trace.rs:
+		// 281-282, :315-318).  Outside the class — an Emission of (inf, 0, 0), a NaN or infinite colour / position / normal, coordinates so large that a
+		// hit point overflows, a sphere of radius 0 (normalize(P - centre) of a hit at the centre), a material of roughness 0 (geometry_schlick_ggx is
+		// 0 / 0 for a surface seen from behind, :372-378) — the reference's sample can be NaN without any mesh, so flags 0 traces such a scene's
+		// black paths on, as it does a scene with a grid (make_params).
+		{
+			auto tame = [](double v) { return std::fabs(v) <= 1e150; }; // finite, and no sum or product of two of them overflows
+			bool ok = true;
+			if (o.geometry_kind != RMD_GEOM_GRID)
+				for (int a = 0; a < 3; a++) ok = ok && tame(o.origin[a]);
+			if (o.geometry_kind == RMD_GEOM_PLANE)
+				for (int a = 0; a < 3; a++) ok = ok && tame(o.normal[a]);
+			if (o.geometry_kind == RMD_GEOM_SPHERE) ok = ok && tame(o.radius) && o.radius != 0.0 && o.radius * o.radius > 0.0;
+			for (int a = 0; a < 3; a++) ok = ok && tame(o.material.color[a]);
+			if (o.material.kind != RMD_MAT_EMISSION) ok = ok && tame(o.material.roughness) && o.material.roughness != 0.0;
+			regular = regular && ok;
+		}
 		if (o.material.kind == RMD_MAT_DIFFUSE && o.material.color[0] == 0.0 && o.material.color[1] == 0.0 && o.material.color[2] == 0.0) d.flags |= rmd::kObjBlackDiffuse;
 	}
 	// pair_opposite_planes: plane j is tested together with the first earlier, still unpaired plane i whose normal is its exact negation
@@ -252,9 +319,9 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 			break;
 		}
 	}
-	rmd_scene *sc = new (std::nothrow) rmd_scene();
+	sc = new (std::nothrow) rmd_scene();
 	if (!sc) return rmd::fail(ctx, RMD_ERR_OUT_OF_MEMORY, "rmd_scene_create: allocation failed");
-	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids;
+	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids, sc->regular = regular;
 	for (uint32_t i = 0; i < n_objects; i++) sc->n_grid_objects += objects[i].geometry_kind == RMD_GEOM_GRID ? 1u : 0u;
 	auto upload = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
 		*dst = nullptr;
@@ -268,7 +335,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 	do {                                                                                        \
 		hipError_t e_ = (call);                                                                 \
 		if (e_ != hipSuccess) {                                                                 \
-			rmd_scene_destroy(sc);                                                              \
+			rmd_scene_destroy(sc), sc = nullptr;                                                              \
 			return rmd::fail(ctx, e_ == hipErrorOutOfMemory ? RMD_ERR_OUT_OF_MEMORY : RMD_ERR_HIP, \
 			                 std::string("rmd_scene_create: ") + hipGetErrorString(e_));         \
 		}                                                                                       \
@@ -281,20 +348,20 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		std::memset(&d, 0, sizeof(d));
 		if (!g.cells || !g.mapping_table || !g.tri_pos || !g.tri_nrm || g.n_tris == 0 ||
 		    g.n_cells != (uint64_t)g.resolution[0] * g.resolution[1] * g.resolution[2]) {
-			rmd_scene_destroy(sc);
+			rmd_scene_destroy(sc), sc = nullptr;
 			return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: inconsistent grid description");
 		}
 		// validate the CSR-like table so that the kernel's gathers stay in bounds
 		for (uint64_t c = 0; c < g.n_cells; c++) {
 			uint64_t off = g.cells[c];
 			if (off >= g.n_mapping || off + (uint64_t)g.mapping_table[off] >= g.n_mapping) {
-				rmd_scene_destroy(sc);
+				rmd_scene_destroy(sc), sc = nullptr;
 				return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table run out of range");
 			}
 			uint32_t cnt = g.mapping_table[off];
 			for (uint32_t k = 1; k <= cnt; k++)
 				if (g.mapping_table[off + k] >= g.n_tris) {
-					rmd_scene_destroy(sc);
+					rmd_scene_destroy(sc), sc = nullptr;
 					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: triangle index out of range in mapping_table");
 				}
 		}
@@ -306,7 +373,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		// the kernel keeps the reference's linear cell index x + res.x*(y + z*res.z) in 32 bits
 		if ((uint64_t)g.resolution[0] * ((uint64_t)g.resolution[1] + (uint64_t)g.resolution[2] * g.resolution[2]) >= (1ull << 31) ||
 		    g.n_cells > (1ull << 31)) {
-			rmd_scene_destroy(sc);
+			rmd_scene_destroy(sc), sc = nullptr;
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: grid resolution too large for 31-bit cell indices");
 		}
 		// triangle records, per-cell lists of triangle indices and the cell entries (device_types.hpp): record = v0, edge1 = v1 - v0,
@@ -314,7 +381,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		// that list without the triangles the cell at index c - delta_s lists too (the cell a walk came from: tested already, missed)
 		const uint64_t n_refs = g.n_mapping - g.n_cells;
 		if (n_refs > 0xFFFFFFFFull) {
-			rmd_scene_destroy(sc);
+			rmd_scene_destroy(sc), sc = nullptr;
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: more than 2^32-1 cell->triangle references");
 		}
 		std::vector<unsigned char> recs((size_t)g.n_tris * rmd::kTriRecStride, 0);
@@ -333,7 +400,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 				const uint32_t off = g.cells[c], cnt = g.mapping_table[off];
 				refs_seen += cnt;
 				if (refs_seen > n_refs) { // cells sharing a run: the tables are not the builder's; refuse rather than overflow
-					rmd_scene_destroy(sc);
+					rmd_scene_destroy(sc), sc = nullptr;
 					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table runs overlap");
 				}
 				entries[c * rmd::kEntrySlots] = rmd::CellEntry{(uint32_t)ids.size(), cnt};
@@ -364,7 +431,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 					e = rmd::CellEntry{(uint32_t)ids.size(), (uint32_t)fresh.size()};
 					ids.insert(ids.end(), fresh.begin(), fresh.end());
 					if (ids.size() > 0xFFFFFFFFull) {
-						rmd_scene_destroy(sc);
+						rmd_scene_destroy(sc), sc = nullptr;
 						return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: triangle index lists exceed 2^32 entries");
 					}
 				}
@@ -384,7 +451,7 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 		if (budget_bytes > rmd::kMaskBudgetBytes) budget_bytes = rmd::kMaskBudgetBytes;
 		const size_t budget_words = budget_bytes / 4 / n_grids;
 		if (budget_words < 2) { // one data word + the all-zero pad word is the smallest mask
-			rmd_scene_destroy(sc);
+			rmd_scene_destroy(sc), sc = nullptr;
 			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: too many grids for the LDS occupancy-mask budget");
 		}
 		if ((g.n_cells + 31) / 32 + 1 <= budget_words) covered = g.n_cells;
@@ -422,7 +489,24 @@ rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_
 	sc->d_grids = (rmd::DevGrid *)p;
 #undef RMD_SCENE_HIP
 	*out = sc;
+	sc = nullptr; // handed over
 	return RMD_OK;
+}
+
+rmd_status rmd_scene_create(rmd_context *ctx, const rmd_object *objects, uint32_t n_objects, const rmd_grid_desc *grids, uint32_t n_grids,
+                            rmd_scene **out) {
+	rmd_scene *sc = nullptr;
+	try {
+		return scene_create_impl(ctx, objects, n_objects, grids, n_grids, out, sc);
+	} catch (const std::bad_alloc &) {
+		if (sc) rmd_scene_destroy(sc);
+		if (out) *out = nullptr;
+		return rmd::fail(ctx, RMD_ERR_OUT_OF_MEMORY, "rmd_scene_create: the host ran out of memory building the scene's tables");
+	} catch (const std::exception &e) { // nothing throws across the boundary
+		if (sc) rmd_scene_destroy(sc);
+		if (out) *out = nullptr;
+		return rmd::fail(ctx, RMD_ERR_HIP, std::string("rmd_scene_create: ") + e.what());
+	}
 }
 
 void rmd_scene_destroy(rmd_scene *scene) {
@@ -461,7 +545,7 @@ rmd_status rmd_framebuffer_download(rmd_context *ctx, const double *dev, double 
 	if (!dev || !host) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_download: null pointer");
 	RMD_HIP(ctx, hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	return RMD_OK;
+	return rmd::check_fault(ctx); // a frame cut short by a device fault is not handed out as a result
 }
 rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *dev, size_t n) {
 	if (rmd_status s = bind(ctx)) return s;
@@ -588,8 +672,10 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			RMD_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, (size_t)P.n_work * sizeof(uint32_t), ctx->stream));
 			Q.tile_done = ctx->d_tile_done;
 		}
-		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent_pass ? ctx->n_cus : 0u));
-		ctx->last_launch.passes++, ctx->last_launch.split_k = Q.split_k, ctx->last_launch.persistent = persistent_pass ? 1u : 0u;
+		rmd::LaunchShape shape;
+		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent_pass ? ctx->n_cus : 0u, &shape));
+		ctx->last_launch.passes++, ctx->last_launch.split_k = Q.split_k;
+		ctx->last_launch.persistent = shape.persistent, ctx->last_launch.waves_per_workgroup = shape.waves_per_wg; // the form it was launched in, not the one asked for
 		if (settings->sample_count == 0) break;
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -633,7 +719,7 @@ rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, u
 rmd_status rmd_context_synchronize(rmd_context *ctx) {
 	if (rmd_status s = bind(ctx)) return s;
 	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	return RMD_OK;
+	return rmd::check_fault(ctx);
 }
 
 rmd_status rmd_render_tiles(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
@@ -662,7 +748,7 @@ rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms) {
 	if (!ctx->timed) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_last_kernel_ms: no render has been enqueued on this context");
 	RMD_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
 	RMD_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
-	return RMD_OK;
+	return rmd::check_fault(ctx);
 }
 
 rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out) {

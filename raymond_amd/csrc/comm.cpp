@@ -28,10 +28,11 @@ namespace {
 
 // RCCL shares device buffers between the ranks of a node through HIP IPC.  On hosts whose driver offers dmabuf IPC only (this pool's: without
 // it ncclCommInitRank fails with `hipIpcGetMemHandle: invalid argument`) the HSA runtime must see HSA_ENABLE_IPC_MODE_LEGACY=0 — and it reads
-// its environment once, at the process's first HIP call.  Loading this library is normally earlier than that, so the variable is given its
-// value here UNLESS the caller has set one (no overwrite); a process that makes HIP calls before it loads the library exports it itself
-// (include/raymond_hip.h, rmd_comm_create).
-__attribute__((constructor)) void rmd_default_ipc_mode() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", /*overwrite=*/0); }
+// its environment once, at the process's first HIP call.  The library does NOT touch the environment by itself (round 4 did, from a load-time
+// constructor: that changed the HSA runtime's behaviour for single-GPU callers and for every other HIP user of the process, and raced with
+// getenv in other threads).  A multi-GPU caller opts in with rmd_comm_prepare_process() before its first HIP call, or exports the variable;
+// rmd_comm_create names the variable when RCCL's initialisation fails without it.
+constexpr const char *kIpcVar = "HSA_ENABLE_IPC_MODE_LEGACY";
 
 struct Rccl {
 	void *handle = nullptr;
@@ -74,6 +75,11 @@ rmd_status rccl_fail(rmd_context *ctx, const char *what, ncclResult_t e) {
 
 extern "C" {
 
+rmd_status rmd_comm_prepare_process(void) {
+	if (setenv(kIpcVar, "0", /*overwrite=*/0) != 0) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_comm_prepare_process: setenv failed");
+	return RMD_OK;
+}
+
 rmd_status rmd_comm_unique_id(uint8_t id_out[RMD_COMM_ID_BYTES]) {
 	if (!id_out) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_comm_unique_id: null pointer");
 	Rccl &r = rccl();
@@ -100,6 +106,11 @@ rmd_status rmd_comm_create(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES]
 	ncclResult_t e = r.CommInitRank(&c->comm, world_size, uid, rank);
 	if (e != ncclSuccess) {
 		delete c;
+		if (world_size > 1 && std::getenv(kIpcVar) == nullptr)
+			return rmd::fail(ctx, RMD_ERR_RCCL, std::string("ncclCommInitRank: ") + r.GetErrorString(e) +
+			                                        " — HSA_ENABLE_IPC_MODE_LEGACY is not set in this process: on hosts whose driver offers dmabuf IPC only, every rank "
+			                                        "needs HSA_ENABLE_IPC_MODE_LEGACY=0 before its first HIP call (export it, or call rmd_comm_prepare_process() before "
+			                                        "rmd_context_create)");
 		return rccl_fail(ctx, "ncclCommInitRank", e);
 	}
 	*out = c;
@@ -116,16 +127,23 @@ void rmd_comm_destroy(rmd_comm *comm) {
 	delete comm;
 }
 
-rmd_status rmd_reduce_framebuffer(rmd_comm *comm, double *accum_dev, size_t n_doubles, int32_t root) {
+rmd_status rmd_reduce_framebuffer_async(rmd_comm *comm, double *accum_dev, size_t n_doubles, int32_t root) {
 	if (!comm || !accum_dev || root < 0 || root >= comm->world) return rmd::fail(comm ? comm->ctx : nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_reduce_framebuffer: bad argument");
 	rmd_context *ctx = comm->ctx;
 	hipError_t he = hipSetDevice(ctx->device);
 	if (he != hipSuccess) return rmd::fail(ctx, RMD_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
+	// on the context's stream: ordered behind the renders enqueued before it, in front of whatever the caller enqueues next
 	ncclResult_t e = rccl().Reduce(accum_dev, accum_dev, n_doubles, ncclDouble, ncclSum, root, comm->comm, ctx->stream);
 	if (e != ncclSuccess) return rccl_fail(ctx, "ncclReduce", e);
-	he = hipStreamSynchronize(ctx->stream);
-	if (he != hipSuccess) return rmd::fail(ctx, RMD_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(he));
 	return RMD_OK;
+}
+
+rmd_status rmd_reduce_framebuffer(rmd_comm *comm, double *accum_dev, size_t n_doubles, int32_t root) {
+	if (rmd_status s = rmd_reduce_framebuffer_async(comm, accum_dev, n_doubles, root)) return s;
+	rmd_context *ctx = comm->ctx;
+	hipError_t he = hipStreamSynchronize(ctx->stream);
+	if (he != hipSuccess) return rmd::fail(ctx, RMD_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(he));
+	return rmd::check_fault(ctx); // the frames that were summed came from launches that may have been cut short
 }
 
 } // extern "C"

@@ -106,7 +106,20 @@ struct RenderParams {
 	uint32_t *tile_done;                // split launches: finished waves per wave tile (zeroed by the host); the last one adds the tile's samples
 	uint32_t end_black_paths;           // 1: a path whose throughput is exactly (0, 0, 0) is ended — scenes without grids unless RMD_RENDER_TRACE_BLACK_PATHS, scenes with grids only with RMD_RENDER_END_BLACK_PATHS (api.cpp: make_params)
 	uint32_t walk_cut;                  // K: a walk call puts the walks of its last K lanes aside for the wave's next call (grid_walk.hpp); 0 = never.  Any value gives the same image
+	uint32_t shade_last_depth;          // 1: the hit at the bounce limit is shaded although its result is its weight times the zero the recursive call returns
+	                                    // (src/trace.rs:235-237) — a scene outside the regular parameter class (api.cpp: rmd_scene::regular), where that weight can be
+	                                    // NaN with finite inputs (roughness 0: 0 / 0 in geometry_schlick_ggx) and the reference's sample NaN x 0 = NaN
+	uint32_t _pad0;
+	uint32_t *fault;                    // the context's fault words (host memory mapped into the device's address space; kFault*): a wave whose loop runs past
+	                                    // its bound reports here, poisons work_counter so that the launch drains, and leaves (render_kernel.hpp: report_fault)
 };
+// Fault words: [0] OR of the kFault* codes, [1] the work item (or list entry) of the wave that reported last, [2] number of reports.
+constexpr uint32_t kFaultTripLoop = 1u;       // render_wave's trip loop (lane-per-path form: direct mode, the mesh kernel, the list probes)
+constexpr uint32_t kFaultSortedTripLoop = 2u; // render_wave_sorted's trip loop (role-sorted spheres kernel)
+constexpr uint32_t kFaultWorkLoop = 4u;       // a persistent wave drew more work items than the launch has
+constexpr uint32_t kFaultWalkRounds = 8u;     // a grid walk call ran more rounds than a ray can take steps (grid_walk.hpp)
+constexpr uint32_t kFaultWords = 4u;
+constexpr uint32_t kWorkCounterPoison = 0x80000000u; // OR-ed into the work counter by a faulting wave: every later draw is past the last item (items are < 2^31: api.cpp)
 
 // List mode (probe): one lane per explicit (x, y, sample).
 struct ListWork {

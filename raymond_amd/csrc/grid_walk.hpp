@@ -59,6 +59,7 @@ RMD_DEV uint32_t wave_scan_add(uint32_t v) {
 	return v;
 }
 RMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+RMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 RMD_DEV uint32_t wave_scan_max(uint32_t v) {
 	v = umax(v, dpp_from<0x111, 0xf>(v));
 	v = umax(v, dpp_from<0x112, 0xf>(v));
@@ -461,7 +462,8 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		if (*carried && walking) { // the walk goes on where the previous call left it
 			tmx = carry->tm[0][lane], tmy = carry->tm[1][lane], tmz = carry->tm[2][lane];
 			idx = carry->idx[lane], prev = carry->prev[lane];
-			remx = carry->rem[0][lane], remy = carry->rem[1][lane], remz = carry->rem[2][lane];
+			// (clamped to what a fresh walk could hold: the counters are this call's loop bound, and LDS is not to be trusted with that)
+			remx = umin(carry->rem[0][lane], (uint32_t)rx + 1u), remy = umin(carry->rem[1][lane], (uint32_t)ry + 1u), remz = umin(carry->rem[2][lane], (uint32_t)rz + 1u);
 		}
 		*carried = false;
 	}
@@ -485,6 +487,12 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 #endif
 	if (count_events && lane == 0) atomicAdd(&dbg[0], 1ull), atomicAdd(&dbg[1], (unsigned long long)__popcll(__ballot(walking)) * 0ull);
 	if (count_events) { unsigned long long wm = __ballot(walking); if (lane == 0) { atomicAdd(&dbg[1], (unsigned long long)__popcll(wm)); if (wm) atomicAdd(&dbg[2], 1ull); } }
+	// The round loop needs no counter of its own: it is bounded by the rays' exit counters.  A round's stepping loop runs its body at least once
+	// for every lane that is still walking (both forms test their condition at the END of an iteration), every step uses up one unit of one of the
+	// lane's three counters, a counter that is used up ends the walk, and the counters start at no more than res + 1 each (steps_to_exit; a
+	// carried walk's are clamped to that when they are loaded): after at most res.x + res.y + res.z + 3 rounds no lane walks, whatever the
+	// candidates yield and whatever the memory holds.  (A counter was tried: 5 more spilled registers in the loop that runs at the kernel's
+	// register limit.)  What a wave does BETWEEN its walk calls is watched by render_wave's stall watch.
 	for (;;) {
 		// 1. per lane: step along the ray (ALU + LDS only), recording up to kWalkCand candidate cells (mask bit set).
 		//    A candidate is stepped over at once — speculating that it yields no hit — so that one round can gather the

@@ -38,6 +38,9 @@ struct rmd_context {
 	uint32_t *d_tile_done = nullptr;    // split launches: finished waves per wave tile (render_kernel.hpp)
 	size_t tile_done_words = 0;
 	unsigned long long *d_debug_counters = nullptr; // walk diagnostics (DIAG builds, RMD_DEBUG=8|16)
+	// fault words (device_types.hpp: kFault*): pinned host memory mapped into the device's address space.  A wave whose loop runs past its bound
+	// writes here; the host looks after every wait for the stream (api.cpp: check_fault) — a plain host load, no copy
+	uint32_t *h_fault = nullptr, *d_fault = nullptr;
 	// Tunables (include/raymond_hip.h: rmd_context_set_tunable).  Defaults come from the environment, read ONCE when the
 	// context is created; none of them changes a result.
 	int64_t tunable[RMD_TUNE_COUNT] = {};
@@ -50,6 +53,7 @@ struct rmd_scene {
 	uint32_t n_objects = 0, n_grids = 0;
 	uint32_t n_grid_objects = 0; // objects whose geometry is a grid
 	uint32_t mask_words_total = 0; // LDS words of the grids' occupancy masks
+	bool regular = true; // every parameter the kernel reads is finite and inside the class for which ending zero-throughput paths is exact (api.cpp: rmd_scene_create)
 	rmd::DevObject *d_objects = nullptr;
 	rmd::DevGrid *d_grids = nullptr;
 	std::vector<void *> owned; // every device allocation of this scene
@@ -90,4 +94,8 @@ inline void triangle_aux(const double *p9, double out[4]) {
 }
 // Records `text` as the last error of `ctx` (or of the calling thread when ctx is null) and returns `status`.
 rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text);
+#ifdef RMD_WITH_HIP
+// After a wait for the context's stream: RMD_ERR_DEVICE_FAULT (and the fault words cleared) when a wave of a launch reported one, else RMD_OK.
+rmd_status check_fault(rmd_context *ctx);
+#endif
 } // namespace rmd

@@ -88,15 +88,15 @@ uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total) {
 }
 
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
-                               const WaveTile *wave_tiles, double *accum, uint32_t n_cus) {
+                               const WaveTile *wave_tiles, double *accum, uint32_t n_cus, LaunchShape *shape) {
 	if (P.n_work == 0) return hipSuccess;
 	const uint32_t n_waves = P.n_work * (P.split_k > 1u ? P.split_k : 1u);
 	const bool buffered = P.split_k > 1u;
 	hipError_t e;
-	if (P.n_grids) e = buffered ? launch_render<kModeTilesBuffered, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus)
-	                            : launch_render<kModeTiles, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus);
-	else e = buffered ? launch_render<kModeTilesBuffered, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus)
-	                  : launch_render<kModeTiles, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus);
+	if (P.n_grids) e = buffered ? launch_render<kModeTilesBuffered, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus, shape)
+	                            : launch_render<kModeTiles, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus, shape);
+	else e = buffered ? launch_render<kModeTilesBuffered, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus, shape)
+	                  : launch_render<kModeTiles, false>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus, shape);
 	if (e != hipSuccess || !buffered || P.tile_done != nullptr) return e; // with tile_done the render kernel's waves add the samples themselves
 	hipLaunchKernelGGL(sum_kernel, dim3(P.n_work), dim3(64), 0, stream, P, wave_tiles, (const double *)P.sample_buf, accum);
 	return hipGetLastError();

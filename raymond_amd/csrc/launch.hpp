@@ -8,6 +8,8 @@
 
 // entries per lane in the list-mode path record: one per trace() depth, bounce_limit <= 16
 #define RMD_PATH_STRIDE 17
+// include/raymond_hip.h: RMD_MAX_BOUNCE_LIMIT (api.cpp asserts the two agree) — a path has at most this many segments, which bounds the render loops
+#define RMD_MAX_BOUNCE_LIMIT_DEV 16u
 
 namespace rmd {
 
@@ -43,6 +45,8 @@ constexpr uint32_t kWalkBatchDefault = 32;
 constexpr uint32_t kWalkCutDefault = 4;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
 constexpr double kMaxRoughness = 512.0;
+// smallest non-zero |roughness|: the specular weight's denominator holds (roughness^2 / 8)^2 (device_core.hpp: next_ray), which must not underflow
+constexpr double kMinRoughness = 1e-12;
 // waves per workgroup of the grid instantiation (they share the LDS occupancy masks)
 // 4-wave workgroups: 4 of them (16 waves) fit a CU's LDS beside their staged masks and retire at a finer grain than 8-wave ones
 #ifndef RMD_GRID_WAVES
@@ -67,11 +71,17 @@ constexpr uint32_t kGridPersistWavesPerWg = RMD_GRID_PERSIST_WAVES; // ... of th
 #define RMD_SORT_WGS_PER_CU 1 // persistent workgroups per CU (a workgroup holds at most 16 waves)
 #endif
 constexpr size_t kSortPoolBytes = 86u * RMD_SORT_SLOTS; // per-wave LDS (sizeof(SortPool))
+// every wave's LDS area ends with 16 bytes of bookkeeping (render_kernel.hpp: word 0 = 1 + the work item a persistent wave drew last)
+constexpr size_t kWaveHeadBytes = 16u;
+// the form a render launch was made in (render_kernel.hpp: launch_render) -> rmd_launch_info
+struct LaunchShape {
+	uint32_t persistent = 0, waves_per_wg = 0;
+};
 size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg);
 uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total);
 // n_cus > 0 and P.work_counter set: grid scenes run as persistent workgroups (render_kernel.hpp)
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
-                               const WaveTile *wave_tiles, double *accum, uint32_t n_cus = 0);
+                               const WaveTile *wave_tiles, double *accum, uint32_t n_cus = 0, LaunchShape *shape = nullptr);
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub);
 // pixel += the per-sample radiance of a split launch, in sample order (kernels.hip: sum_kernel)

@@ -13,7 +13,8 @@ namespace rmd {
 // LDS per wave: the cooperative-walk scratch, only when the scene has grids.
 // per-wave LDS of the grid kernel: the walk scratch and the 64 paths' throughput (3 doubles per lane)
 // ... and the DDA states of walks put aside for the wave's next walk call (grid_walk.hpp: WalkCarry)
-__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) + sizeof(WalkCarry) : 0; }
+// ... and the wave's 16 bytes of bookkeeping behind them (launch.hpp: kWaveHeadBytes)
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return kWaveHeadBytes + (n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) + sizeof(WalkCarry) : 0); }
 
 // Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
 // reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
@@ -24,6 +25,33 @@ RMD_DEV uint32_t work_item_of_block(uint32_t b, uint32_t nb) {
 	(void)nb;
 	return b;
 }
+
+// Every loop of the render kernel has a bound that no input reaches (each one's comment says why).  A wave that nevertheless runs into one —
+// a fault of this library, or memory it relies on overwritten — must not spin (the reference's own failure mode: `TaskHandle::await` polls for
+// ever after a worker's panic, src/trace.rs:82-92) and must not end quietly with a frame that looks valid either: it ORs the loop's code into
+// the context's fault word (host memory the device writes through: the host reads it after the launch and returns RMD_ERR_DEVICE_FAULT,
+// api.cpp: check_fault), poisons the launch's work counter so that no wave draws another item, and leaves.
+RMD_DEV void report_fault(const RenderParams &P, uint32_t code, uint32_t detail) {
+	if ((threadIdx.x & 63u) == 0u) {
+		if (P.fault != nullptr) {
+			__hip_atomic_fetch_or(P.fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(P.fault + 1, detail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_fetch_add(P.fault + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		if (P.work_counter != nullptr) __hip_atomic_fetch_or(P.work_counter, kWorkCounterPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+// (A/B switches for tools/ab_multi.sh: what the bounds cost — 0 compiles a check out)
+#ifndef RMD_BOUND_TRIPS
+#define RMD_BOUND_TRIPS 1
+#endif
+#ifndef RMD_BOUND_DRAWS
+#define RMD_BOUND_DRAWS 1
+#endif
+// render_wave_sorted: trips a wave may take per (pixel, sample) pair of its work item, as if ONE lane ran them all one after the other (a path has
+// at most RMD_MAX_BOUNCE_LIMIT segments and one more trip ends it; a wave runs its pairs 64 at a time, so a real item takes a fraction of this).
+constexpr uint32_t kTripBoundPerPair = RMD_MAX_BOUNCE_LIMIT_DEV + 4u;
+constexpr uint32_t kStallBound = 1u << 18; // render_wave: trips a wave may take without one of its lanes finishing a sample or being handed one
 
 // core/src/scene.rs:54-74: linear closest hit over the objects; strict '<' keeps the first object on ties.
 // Wave-level: called by all 64 lanes in uniform control flow, `want` marks the lanes that carry a ray.  The object
@@ -273,7 +301,17 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 	bool new_ray = false, waiting = false;
 	bool carried = false; // ... and its walk has begun: put aside by the previous walk call, to be taken up by the next (grid_walk.hpp)
 	[[maybe_unused]] WalkCarry *carry = GRID ? reinterpret_cast<WalkCarry *>(wave_lds + sizeof(WalkScratch) + 64u * 3u * sizeof(double)) : nullptr;
-	uint32_t trips_since_walk = 0; // wave-uniform
+	// wave-uniform, ONE scalar register for two counters (the mesh kernel runs at its register limit: a 64-bit trip count of its own cost 48
+	// more spilled registers): low byte — trips since the wave's last walk call; the rest — the STALL WATCH, trips since a lane of the wave last
+	// finished a sample or was handed a pair.  A path ends after at most RMD_MAX_BOUNCE_LIMIT segments; a segment waits at most kWalkMaxWait
+	// trips for its walk and a walk is put aside at most once per step it still has to take (only calls with >= 16 walkers put walks aside and
+	// each advances every walker: < 256 times): 16 x 256 x 7 < 2^15 trips is the longest any wave can go without one of its lanes finishing a
+	// sample.  kStallBound trips without one (2^18: a few seconds) is a fault (report_fault), whatever the cause.
+	uint32_t trips_since_walk = 0;
+	uint32_t stall_bound = kStallBound << 8;
+#if RMD_DIAG
+	if (P.debug_flags & 32u) stall_bound = 2u << 8; // tests/test_gpu_faults.py: forces the bound
+#endif
 	double part_t = kFMax;
 	int part_obj = -1;
 	uint32_t part_sub = 0;
@@ -322,6 +360,18 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			}
 		};
 		decltype(auto) Pt = trip_params();
+#if RMD_BOUND_TRIPS
+		// (no `break` here: a second way out of this loop cost the mesh kernel 40 spilled registers.  A stalled wave reports, drops every path
+		// and pair it holds and leaves through the loop's own exit below.)
+		trips_since_walk += 0x100u;
+		const bool stalled = trips_since_walk >= stall_bound; // (never true: see trips_since_walk)
+		if (stalled) {
+			report_fault(Pt, kFaultTripLoop, first);
+			complete = false, lens_failed = false, cut = false, has_ray = false, to_shade = false, need_sample = false, alive = false;
+			if constexpr (to_buffer) next_item = pool_items;
+			else s = s_end;
+		}
+#endif
 		// ---------------- (C) the hits the previous trip found (`complete`): miss, emission, or a surface to shade.  The loop is entered here: a
 		// trip is (C) classification -> (B) hand-out and next rays -> (A) intersection; a surface classified here is shaded a few lines
 		// further down, with nothing but the hand-out in between (the mesh kernel: two spilled registers instead of four).
@@ -354,10 +404,11 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 					}
 					// At the bounce limit the recursive call returns 0 at once (:235-237) and this depth's result is its weight times
 					// that zero (:281-282 / :315-318): exactly zero whenever the weight is finite, so the shading is not evaluated.
-					// A weight is non-finite only through a non-finite input — the Heron normal of a degenerate hit, a hit point
-					// at infinity — (then the reference's sample is NaN, and so is this one: the lane shades and multiplies by zero on
-					// its next trip), or through r1 = 0 exactly in the diffuse pdf (probability 2^-53 per path; there the reference
-					// returns NaN and this kernel 0).
+					// In a scene of regular parameters (api.cpp: rmd_scene::regular) a weight is non-finite only through a non-finite input — the
+					// Heron normal of a degenerate hit, a hit point at infinity — (then the reference's sample is NaN, and so is this one: the
+					// lane shades and multiplies by zero on its next trip), or through r1 = 0 exactly in the diffuse pdf (probability 2^-53 per
+					// path; there the reference returns NaN and this kernel 0).  Outside that class — a NaN colour, roughness 0 (0 / 0 in
+					// geometry_schlick_ggx for a surface seen from behind) — the last depth is shaded like any other (shade_last_depth).
 					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
 					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
 					// ... and so is a diffuse bounce off a black surface (o.flags: Diffuse, colour (0, 0, 0)): its weight (1 - F)(1 - metal) (.) colour
@@ -366,7 +417,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 					// now: r is the 22-bit uniform of the path's PREVIOUS block.  The lane takes its next sample on this very trip instead of
 					// shading, finding its throughput zero and sitting out the intersection phase.
 					const bool black_bounce = !LIST && Pt.end_black_paths != 0u && (o.flags & kObjBlackDiffuse) != 0u && lobe_bits < (1u << 21);
-					if ((depth == Pt.bounce_limit || black_bounce) && finite_inputs) {
+					if (((depth == Pt.bounce_limit && Pt.shade_last_depth == 0u) || black_bounce) && finite_inputs) {
 						terminal = true; // L = 0
 					} else {
 						if constexpr (GRID) parked[0] = normal.x, parked[64] = normal.y, parked[128] = normal.z, parked[192] = t, parked_obj[0] = oi;
@@ -400,6 +451,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			has_ray = false;
 			need_sample = true;
 		}
+		if (__ballot(terminal) != 0ull) trips_since_walk &= 0xFFu; // a lane has finished a sample: the stall watch starts again
 		RMD_TSTAMP(tt_class)
 		// ---------------- (B) hand out samples, then rays
 		bool prim = false;
@@ -409,6 +461,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			if (idle != 0ull && next_item < pool_items) {
 				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				next_item += (uint32_t)__popcll(idle);
+				trips_since_walk &= 0xFFu; // pairs handed out: the stall watch starts again
 				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) // slots outside a ragged tile are skipped
 					item = k, prim = true;
 			}
@@ -501,9 +554,9 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			RMD_TSTAMP(tt_simple)
 			// run the grid walks when enough lanes wait for one, or when no lane of the wave could do anything else
 			const unsigned long long wm = __ballot(want && waiting), rm = __ballot(alive && !(want && waiting));
-			trips_since_walk++;
-			if (wm != 0ull && ((uint32_t)__popcll(wm) >= Pt.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || trips_since_walk >= kWalkMaxWait)) {
-				trips_since_walk = 0;
+			if ((trips_since_walk & 0xFFu) != 0xFFu) trips_since_walk++; // (saturating: the byte's neighbours are the stall watch)
+			if (wm != 0ull && ((uint32_t)__popcll(wm) >= Pt.walk_batch || (uint32_t)__popcll(rm) < kWalkMinRunnable || (trips_since_walk & 0xFFu) >= kWalkMaxWait)) {
+				trips_since_walk &= ~0xFFu;
 				// walks are put aside only by a call with many walkers in a wave that has other lanes to run: otherwise every walk is finished
 				if constexpr (MODE != kModeTiles) {
 					const uint32_t n_walkers = (uint32_t)__popcll(wm);
@@ -598,7 +651,11 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 	pool.empty_list[lane] = (uint8_t)lane;
 	if (lane + 64u < kSortSlots) pool.empty_list[lane + 64u] = (uint8_t)(lane + 64u);
 	uint32_t n_empty = kSortSlots, n_hit = 0, next_item = 0; // wave-uniform
-	unsigned long long trips_left = (unsigned long long)pool_items * 20u + 64u; // (a path has at most RMD_MAX_BOUNCE_LIMIT = 16 segments)
+	// the trip loop's bound (report_fault): every trip hands out at least one pair or advances at least one path by a segment
+	unsigned long long trips_left = (unsigned long long)pool_items * kTripBoundPerPair + 64ull;
+#if RMD_DIAG
+	if (P.debug_flags & 32u) trips_left = 1ull; // tests/test_gpu_faults.py: forces the bound
+#endif
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	for (;;) {
@@ -618,10 +675,20 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		const RenderParams &Pt = P;
 #endif
 
-		// which kind of trip: shade when 64 hits wait, else start samples while the item has any, else shade what is left
+		// which kind of trip: shade when 64 hits wait, else start samples while the item has any, else shade what is left.
+		// Every trip makes progress, for every pool size the static_assert admits (64 .. 256 slots).  Between trips n_empty + n_hit = kSortSlots
+		// >= 64: every slot a trip takes comes back to one of the two lists at its end.  A shading trip has min(n_hit, 64) lanes and is chosen
+		// when n_hit >= 64, or no pair is left (n_hit > 0 then, else the loop has ended), or n_empty < 64 and n_hit >= n_empty — then n_hit >=
+		// kSortSlots - 63 >= 1: at least one path advances by a segment, and a path has at most bounce_limit of them.  Otherwise pairs are left
+		// and n_empty >= 64 or n_empty > n_hit >= 0: the trip hands out min(n_empty, 64) >= 1 pairs (next_item grows).  There is no state in
+		// which a trip runs with no lane — unlike a pool with THREE lists, where all three can be short of a full trip while the empty list
+		// holds nothing (tools/experiments/README.md: the run that was killed for silence in round 4).
+		if (trips_left-- == 0ull) { // (never reached: see above) — the wave reports, drops what it holds and leaves through the loop's own exit
+			report_fault(Pt, kFaultSortedTripLoop, work_item);
+			n_hit = 0u, next_item = pool_items;
+		}
 		const bool items_left = next_item < pool_items;
 		if (n_hit == 0u && !items_left) break;
-		if (trips_left-- == 0ull) break; // (never reached: every trip hands out a pair or advances a path by a segment — the bound gives the wave an exit whatever happens)
 		// (a full trip of either kind when one list holds 64 slots — always, with 127 slots or more; else the longer list)
 		const bool shade_trip = n_hit >= 64u || !items_left || (n_empty < 64u && n_hit >= n_empty);
 		bool active;
@@ -700,7 +767,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
 					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
 					const bool black_bounce = Pt.end_black_paths != 0u && (o.flags & kObjBlackDiffuse) != 0u && rng.lobe_bits < (1u << 21);
-					if ((depth == Pt.bounce_limit || black_bounce) && finite_inputs) terminal = true; // L = 0
+					if (((depth == Pt.bounce_limit && Pt.shade_last_depth == 0u) || black_bounce) && finite_inputs) terminal = true; // L = 0
 					else park = true;
 				}
 			}
@@ -741,7 +808,7 @@ template <int MODE, bool GRID>
 constexpr bool kSortedTrips = RMD_SORTED_TRIPS && MODE == kModeTilesBuffered && !GRID;
 // LDS of one wave of an instantiation
 template <int MODE, bool GRID>
-__host__ __device__ inline size_t wave_lds_of(uint32_t n_grids) { return kSortedTrips<MODE, GRID> ? sizeof(SortPool) : wave_lds_bytes(n_grids); }
+__host__ __device__ inline size_t wave_lds_of(uint32_t n_grids) { return kSortedTrips<MODE, GRID> ? kWaveHeadBytes + sizeof(SortPool) : wave_lds_bytes(n_grids); }
 template <int MODE, bool GRID>
 constexpr uint32_t kPersistWaves = kSortedTrips<MODE, GRID> ? kSortedWavesPerWg : GRID ? kGridPersistWavesPerWg : kPersistWavesPerWg;
 template <int MODE, bool GRID, bool PERSIST>
@@ -757,8 +824,12 @@ __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ?
 	DevObject *lobjs = reinterpret_cast<DevObject *>(smem);
 	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem + (size_t)P.n_objects * sizeof(DevObject));
 	const uint32_t tid = threadIdx.x, wave = tid >> 6, waves_per_wg = blockDim.x >> 6;
+	// a wave's area: the instantiation's own data, then 16 bytes more — word 0: 1 + the work item the wave drew last (persistent form).  (Behind
+	// the data, not in front: the mesh kernel's register allocation is at its limit, and with the data 16 bytes further on it came out with 22
+	// spilled registers instead of 13.)
 	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
 	                          (size_t)wave * wave_lds_of<MODE, GRID>(P.n_grids);
+	[[maybe_unused]] unsigned char *wave_head = wave_lds + wave_lds_of<MODE, GRID>(P.n_grids) - kWaveHeadBytes;
 	// stage the object table and the occupancy masks: coalesced, once per workgroup
 	{
 		const double *src = reinterpret_cast<const double *>(objs);
@@ -775,11 +846,32 @@ __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ?
 	if constexpr (PERSIST) {
 		static_assert(MODE != kModeList, "list launches are not persistent");
 		const uint32_t n_items = P.n_work * (MODE == kModeTilesBuffered ? P.split_k : 1u);
+		// The work loop's bound.  The counter only grows, so every draw of a wave is larger than its last one and the draws that pass the test
+		// below are fewer than n_items: the loop ends by itself.  What is checked is the premise — a draw that is NOT larger than the wave's last
+		// (the counter was overwritten: items would be rendered twice, for ever) is a fault.  The last draw + 1 lives in the wave's LDS head,
+		// not in a register (the mesh kernel runs at its register limit); a faulting wave ORs kWorkCounterPoison into the counter, which ends
+		// every other wave's loop at its next draw.
+		volatile uint32_t *last_draw = reinterpret_cast<volatile uint32_t *>(wave_head);
+		if ((tid & 63u) == 0u) *last_draw = 0u;
 		for (;;) {
-			uint32_t item = 0;
-			if ((tid & 63u) == 0u) item = atomicAdd(P.work_counter, 1u);
+			uint32_t item = 0, floor = 0;
+			if ((tid & 63u) == 0u) {
+				item = atomicAdd(P.work_counter, 1u);
+				floor = *last_draw;
+				*last_draw = item + 1u;
+#if RMD_DIAG
+				if ((P.debug_flags & 128u) && floor != 0u) floor = 0xFFFFFFFFu; // tests/test_gpu_faults.py: forces the bound at a wave's second draw
+#endif
+			}
 			item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
 			if (item >= n_items) break;
+#if RMD_BOUND_DRAWS
+			floor = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor);
+			if (item < floor) { // (never reached)
+				report_fault(P, kFaultWorkLoop, item);
+				break;
+			}
+#endif
 			if constexpr (kSortedTrips<MODE, GRID>) render_wave_sorted(P, kernarg_params, objs, grids, work, out, lobjs, wave_lds, item);
 			else render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
 		}
@@ -792,17 +884,20 @@ __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ?
 
 // n_cus > 0 (tile modes of grid scenes): the persistent form, one 16-wave workgroup per CU (fewer when there are fewer work items);
 // P.work_counter must point at a zeroed device word.
+// `shape` (optional) receives the form the kernel was actually launched in.
 template <int MODE, bool GRID>
 inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
-                                uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub, uint32_t n_cus = 0) {
+                                uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub, uint32_t n_cus = 0, LaunchShape *shape = nullptr) {
 	// LDS of a workgroup of `waves` waves of this instantiation: [object table][grid occupancy masks][per-wave area]
 	auto lds_for = [&](uint32_t waves) {
 		return (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u + (size_t)waves * wave_lds_of<MODE, GRID>(P.mask_words_total ? 1u : 0u);
 	};
 	if constexpr (MODE != kModeList) {
 		uint32_t pw = kPersistWaves<MODE, GRID>;
-		if constexpr (kSortedTrips<MODE, GRID>)
-			while (pw > 4u && lds_for(pw) > kLdsBudgetBytes) pw--; // a large object table leaves room for fewer pools: fewer waves per workgroup
+		// a large object table (128 bytes an object) or several grids' masks leave room for fewer per-wave areas — pools of the spheres kernel,
+		// walk scratch + throughputs + carried walks (6,656 bytes) of the mesh kernel: fewer waves per workgroup (the kernel takes its wave count
+		// from blockDim); below 4 waves the launch runs as one wave per item
+		while (pw > 4u && lds_for(pw) > kLdsBudgetBytes) pw--;
 		if (n_cus != 0u && P.work_counter != nullptr && lds_for(pw) <= kLdsBudgetBytes) {
 			const size_t lds = lds_for(pw);
 			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -811,6 +906,7 @@ inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const
 			const uint32_t wgs = (n_waves + pw - 1u) / pw, resident = n_cus * (kSortedTrips<MODE, GRID> ? RMD_SORT_WGS_PER_CU : 1u);
 			hipLaunchKernelGGL((render_kernel<MODE, GRID, true>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs, grids, work, out,
 			                   path_obj, path_sub);
+			if (shape) shape->persistent = 1u, shape->waves_per_wg = pw;
 			return hipGetLastError();
 		}
 	}
@@ -823,6 +919,7 @@ inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const
 	}
 	hipLaunchKernelGGL((render_kernel<MODE, GRID, false>), dim3((n_waves + wpw - 1u) / wpw), dim3(64u * wpw), lds, stream, P, objs, grids, work, out,
 	                   path_obj, path_sub);
+	if (shape) shape->persistent = 0u, shape->waves_per_wg = wpw;
 	return hipGetLastError();
 }
 

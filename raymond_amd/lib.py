@@ -53,10 +53,12 @@ SIGNATURES = {
         C.c_int32,
         [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp],
     ),
+    "rmd_comm_prepare_process": (C.c_int32, []),
     "rmd_comm_unique_id": (C.c_int32, [_vp]),
     "rmd_comm_create": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _P(_vp)]),
     "rmd_comm_destroy": (None, [_vp]),
     "rmd_reduce_framebuffer": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32]),
+    "rmd_reduce_framebuffer_async": (C.c_int32, [_vp, _vp, C.c_size_t, C.c_int32]),
     "rmd_grid_build_from_mesh": (C.c_int32, [_vp, _vp, C.c_uint64, _P(_vp)]),
     "rmd_grid_build_from_mesh_gpu": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _P(_vp)]),
     "rmd_grid_build_describe": (C.c_int32, [_vp, _P(abi.GridDesc)]),

@@ -176,16 +176,19 @@ def test_every_rank_gets_the_dmabuf_ipc_setting_in_both_launch_forms(form):
         assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == (preset or "0") for e in echoed), echoed
 
 
-def test_the_library_sets_the_ipc_mode_when_it_is_loaded_unless_the_caller_did():
-    """libraymond_hip.so's load-time default for C-ABI callers that use rmd_comm_* (csrc/comm.cpp): HSA_ENABLE_IPC_MODE_LEGACY=0, no overwrite."""
+def test_the_library_leaves_the_environment_alone_until_a_multi_gpu_caller_opts_in():
+    """csrc/comm.cpp: loading libraymond_hip.so does not touch the environment (round 4's load-time constructor did: it changed the HSA runtime's
+    behaviour for single-GPU callers and every other HIP user of the process); rmd_comm_prepare_process() — what a multi-GPU C-ABI caller invokes
+    before its first HIP call — sets HSA_ENABLE_IPC_MODE_LEGACY=0 and never overwrites a value the caller chose."""
     import subprocess
 
     from raymond_amd import lib
 
     # (os.environ is a snapshot taken at interpreter start: read the C environment)
-    code = ("import ctypes; ctypes.CDLL(%r); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
-            "print(libc.getenv(b'HSA_ENABLE_IPC_MODE_LEGACY').decode())" % lib.LIB_PATH)
-    for preset, want in ((None, "0"), ("1", "1")):
+    code = ("import ctypes; L = ctypes.CDLL(%r); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "show = lambda: (libc.getenv(b'HSA_ENABLE_IPC_MODE_LEGACY') or b'unset').decode(); a = show(); "
+            "assert L.rmd_comm_prepare_process() == 0; print(a, show())" % lib.LIB_PATH)
+    for preset, want in ((None, "unset 0"), ("1", "1 1")):
         env = dict(os.environ)
         env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
         if preset is not None:

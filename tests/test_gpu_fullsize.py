@@ -21,6 +21,73 @@ def rel_close(a, b, rtol):
     return (np.abs(a - b) <= rtol * np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-300)) | (a == b) | (np.isnan(a) & np.isnan(b))
 
 
+def account_for_off_pixels(gpu_ctx, oracle, sc, st, cam, spp, frame, ref, ok, label, limit=1e-4):
+    """Every pixel of `frame` (the production kernel's) that is NOT within 1e-9 of the oracle's `ref` is accounted for, sample by sample: its
+    samples are traced again one by one — by the device through the list probe (the render kernel's own code on an explicit (x, y, sample)
+    list, vertex sequence recorded) and by the oracle — and
+      (1) the production pixel is, bit for bit, the sequential sum of the device's per-sample values (src/trace.rs:203: nothing but samples went in),
+      (2) the oracle's pixel is the sequential sum of the oracle's per-sample values,
+      (3) every sample whose vertex sequence is the same on both sides agrees to 1e-9 relative OR 1e-12 absolute.  (Round 5 found what the second
+          clause is for: 2 of the 265 M samples of the C2 frame keep their vertex sequence and differ by 1.8e-9 / 2.6e-9 relative — 7e-14 absolute:
+          a grazing bounce whose weight carries a cosine n.l ~ 1e-7, so that the 1e-16 by which the device's sin / cos move the direction against
+          the host libm's is 1e-9 of the cosine.  An absolute error of 1e-12 on radiances of order 1 is far inside the stated bar; a relative
+          bar alone cannot hold for a quantity that passes through zero.)  So the pixel's difference beyond that is the sum over the samples
+          whose vertex sequence DIFFERS (an ulp of libm turned a hit into a miss: a flipped sample), and
+      (4) every off pixel holds a flipped sample or a grazing one (same sequence, outside 1e-9 relative, inside 1e-12 absolute).
+    The number of off pixels is bounded by `limit` of the frame (the 1,000,000-sample campaign found 0 flipped samples: profiles/r04_parity_campaign.txt)
+    and the counts are recorded (gpurun_out/r05_off_pixels.jsonl on the GPU box -> profiles/)."""
+    import json
+    import os
+
+    ys, xs = np.nonzero(~ok)
+    n_off, n_px = len(ys), ok.size
+    record = {"case": label, "pixels": int(n_px), "spp": int(spp), "off_pixels": int(n_off), "flipped_samples": 0, "max_flipped_per_off_pixel": 0,
+              "grazing_samples": 0, "max_abs_diff_of_a_grazing_sample": 0.0, "max_rel_diff_of_a_grazing_sample": 0.0}
+    assert n_off <= max(3, limit * n_px), "%s: %d of %d pixels are off" % (label, n_off, n_px)
+    if n_off:
+        xy = np.repeat(np.stack([xs, ys], axis=1), spp, axis=0).astype(np.uint32)
+        smp = np.tile(np.arange(spp, dtype=np.uint32), n_off)
+        ds = render.DeviceScene(gpu_ctx, sc)
+        drgb, dpo, dps = probe.trace_samples(gpu_ctx, ds, cam, st, xy, smp, paths=True)
+        ds.close()
+        osc = oracle.OracleScene(sc)
+        orgb = np.zeros_like(drgb)
+        same_path = np.zeros(len(smp), dtype=bool)
+        for i in range(len(smp)):
+            rgb, po, ps = osc.trace_sample_path(cam, st, int(xy[i, 0]), int(xy[i, 1]), int(smp[i]))
+            orgb[i] = rgb
+            k = len(po)
+            same_path[i] = (dpo[i, :k] == po).all() and (dps[i, :k] == ps).all() and (dpo[i, k:] == -2).all()
+        drgb, orgb, same_path = drgb.reshape(n_off, spp, 3), orgb.reshape(n_off, spp, 3), same_path.reshape(n_off, spp)
+        dsum, osum = np.zeros((n_off, 3)), np.zeros((n_off, 3))
+        for k in range(spp):  # in sample order
+            dsum, osum = dsum + drgb[:, k], osum + orgb[:, k]
+        bits = lambda a, b: ((np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)) | (np.isnan(a) & np.isnan(b))).all()
+        assert bits(frame[ys, xs], dsum), "%s: an off pixel is not the sum of its samples" % label  # (1)
+        assert bits(ref[ys, xs], osum), "%s: the oracle's frame is not the sum of its samples" % label  # (2)
+        absd = np.abs(drgb - orgb)
+        within = rel_close(drgb, orgb, 1e-9) | (absd <= 1e-12)
+        assert within[same_path].all(), "%s: a sample with the oracle's vertex sequence is off" % label  # (3)
+        flipped = (~same_path).sum(axis=1)
+        grazing = same_path & ~rel_close(drgb, orgb, 1e-9).all(axis=2)
+        assert ((flipped >= 1) | grazing.any(axis=1)).all(), "%s: an off pixel with neither a flipped nor a grazing sample" % label  # (4)
+        record["flipped_samples"], record["max_flipped_per_off_pixel"] = int(flipped.sum()), int(flipped.max())
+        if grazing.any():
+            scale = np.maximum(np.maximum(np.abs(drgb), np.abs(orgb)), 1e-300)
+            record["grazing_samples"] = int(grazing.sum())
+            record["max_abs_diff_of_a_grazing_sample"] = float(absd[grazing].max())
+            record["max_rel_diff_of_a_grazing_sample"] = float((absd / scale)[grazing].max())
+    print("off-pixel accounting: %s" % json.dumps(record))
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        if os.path.isdir(os.path.join(root, "gpurun_out")):
+            with open(os.path.join(root, "gpurun_out", "r05_off_pixels.jsonl"), "a") as f:
+                f.write(json.dumps(record) + "\n")
+    except OSError:
+        pass
+    return record
+
+
 @pytest.mark.parametrize("config", ["C3", "C4", "C5"])
 def test_spot_samples_against_the_oracle(gpu_ctx, oracle, dragon, config):
     """8,192 random (pixel, sample) pairs of the full-size configuration vs the oracle, hit sequence included."""
@@ -84,18 +151,22 @@ def test_spot_pixels_of_the_production_kernel_at_full_size(gpu_ctx, oracle, drag
         acc = acc + o[:, k]  # in sample order
     got = full[px[:, 1], px[:, 0]]
     ok = rel_close(got, acc, 1e-9).all(axis=1)
-    assert ok.mean() >= 0.99, ok.mean()
     assert (acc > 0).any(axis=1).mean() > 0.5  # not a comparison of zeros
-    # a pixel that is off is off by whole flipped samples (an ulp-level difference changing a hit sequence), not by garbage
-    assert np.abs(got - acc)[~ok].max(initial=0.0) <= spp * 1.5 * 4
+    # a pixel that is off is off by whole flipped samples (an ulp-level difference changing a hit sequence), each one found and counted
+    ref = np.zeros_like(full)
+    ref[px[:, 1], px[:, 0]] = acc
+    mask = np.ones(full.shape[:2], dtype=bool)
+    mask[px[:, 1], px[:, 0]] = ok
+    rec = account_for_off_pixels(gpu_ctx, oracle, sc, st, cam, spp, full, ref, mask, "spot-pixels %s %d spp %s" % (config, spp, mode), limit=0.0)
+    assert rec["off_pixels"] <= 3
 
 
 @pytest.mark.parametrize("config,spp,mode", [("C2", 128, "default"), ("C3", 16, "default"), ("C3", 16, "end"), ("C4", 8, "default"), ("C5", 8, "default")])
 def test_whole_frame_of_the_production_kernel_against_the_oracle(gpu_ctx, oracle, dragon, config, spp, mode):
     """EVERY pixel of a full-size frame (1920x1080; C4: 3840x2160, 8 bounces; C5: thin lens) rendered by the production instantiation (asserted through rmd_last_launch_info: persistent workgroups,
     samples split over several work items, pooled hand-out, ordered sum) against `oracle.render_tiles` — the reference's loop
-    (src/trace.rs:197-205) on 16 host threads: >= 99.5 % of the pixels within 1e-9, the rest off by whole samples (an ulp-level
-    difference that changed a hit sequence), mean radiance equal to 1e-4.  C2: 265.4 M samples (the spheres kernel splits a tile's samples from 128 per pixel on), flags 0 (zero-throughput paths ended: the scene has
+    (src/trace.rs:197-205) on 16 host threads: every pixel within 1e-9 EXCEPT those — at most 1e-4 of the frame, counted and recorded — that
+    account_for_off_pixels() shows to be off by flipped samples only; mean radiance equal to 1e-4.  C2: 265.4 M samples (the spheres kernel splits a tile's samples from 128 per pixel on), flags 0 (zero-throughput paths ended: the scene has
     no grid); C3: 33.2 M samples with flags 0 (every path traced) and with RMD_RENDER_END_BLACK_PATHS."""
     st = scenes.config_settings(config, spp=spp)
     st.end_black_paths = mode == "end"
@@ -112,8 +183,8 @@ def test_whole_frame_of_the_production_kernel_against_the_oracle(gpu_ctx, oracle
     fb.close(), ds.close()
     ref = oracle.OracleScene(sc, fast=True).render_tiles(cam, st, tiles, threads=16)
     ok = rel_close(dev, ref, 1e-9).all(axis=2)
-    assert ok.mean() >= 0.995, "pixels off: %d of %d" % ((~ok).sum(), ok.size)
-    assert np.abs(dev - ref)[~ok].max(initial=0.0) <= spp * 1.5 * 4
+    # no allowance for unexplained pixels: every pixel outside 1e-9 is re-traced sample by sample and must be off by flipped samples only
+    account_for_off_pixels(gpu_ctx, oracle, sc, st, cam, spp, dev, ref, ok, "whole-frame %s %dx%d %d spp %s" % (config, W, H, spp, mode))
     assert abs(np.nanmean(dev) - np.nanmean(ref)) <= 1e-4 * np.nanmean(ref)
     assert (dev == ref).all(axis=2).mean() > 0.3  # a good share of the pixels is bit-identical, sums included
 

