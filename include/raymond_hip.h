@@ -111,6 +111,9 @@ typedef struct rmd_grid_desc {
 	const double *tri_pos; /* n_tris * 9: v0.xyz v1.xyz v2.xyz          */
 	const double *tri_nrm; /* n_tris * 9: n0.xyz n1.xyz n2.xyz          */
 	uint64_t n_tris;
+	const struct rmd_grid_build *built; /* NULL, or the rmd_grid_build these pointers belong to (set by rmd_grid_build_describe): rmd_scene_create
+	                                       then derives its device tables ONCE per build (about 50 ms of host time for 100k triangles) and
+	                                       every later upload of the same grid — one per render_tiled call and GPU — reuses them       */
 } rmd_grid_desc;
 
 /* CameraSettings (src/trace.rs:32-40) + Transform (src/transform.rs:4-7, position only). */
@@ -217,7 +220,9 @@ enum {
 	                              or whose buffer the device cannot provide — runs as several passes                       */
 	RMD_TUNE_WALK_CUT = 5,     /* RMD_WALK_CUT: K + 1, where a grid-walk call of a wave stops stepping under its last K rays and leaves their
 	                              walks to the wave's next call (0 = the library's choice, K = 4; 1 = every call finishes every walk)      */
-	RMD_TUNE_COUNT = 6
+	RMD_TUNE_SPLIT_MIN_SAMPLES = 6, /* RMD_SPLIT_MIN_SAMPLES: fewest samples per pixel a work item of a split launch may hold (0 = the library's
+	                              choice: 2 in scenes with grids, 64 without).  Launches with fewer than twice that run in direct mode      */
+	RMD_TUNE_COUNT = 7
 };
 /* Free and total memory of the context's device, bytes (hipMemGetInfo): what a host that shares the GPU sizes its launches by. */
 rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, uint64_t *out_total_bytes);
@@ -236,6 +241,24 @@ rmd_status rmd_framebuffer_free(rmd_context *ctx, double *dev);
 rmd_status rmd_framebuffer_zero(rmd_context *ctx, double *dev, size_t n_doubles);
 rmd_status rmd_framebuffer_download(rmd_context *ctx, const double *dev, double *host, size_t n_doubles);
 rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *dev, size_t n_doubles);
+
+/* Tile rectangles of a device framebuffer <-> a PACKED host buffer: rect i's pixels row-major, width * height * 3 doubles, one rect after the
+ * other in the order of `rects` — the layout of core::tile::Tile.data (core/src/tile.rs:13).  What a host scheduler needs to keep the tile sums
+ * resident on the device between progressive passes and move only the tiles a message needs (TileProgressed / TileFinished, src/trace.rs:211-219)
+ * instead of the whole W * H * 3 frame up and down around every call.  Rects must lie inside the W x H frame.
+ * _async: the tiles are packed on the context's stream (behind the renders enqueued before), copied on the context's COPY stream — renders
+ * enqueued afterwards overlap the copy — and are in `host_packed` once rmd_context_wait_transfers has returned; `host_packed` should be pinned
+ * memory (rmd_host_alloc) for the copy to be asynchronous.  At most two such downloads are in flight per context: a third waits for the first. */
+rmd_status rmd_framebuffer_download_tiles(rmd_context *ctx, const double *dev, uint32_t width, uint32_t height, const rmd_tile_rect *rects,
+                                          uint32_t n_rects, double *host_packed);
+rmd_status rmd_framebuffer_download_tiles_async(rmd_context *ctx, const double *dev, uint32_t width, uint32_t height, const rmd_tile_rect *rects,
+                                                uint32_t n_rects, double *host_packed);
+rmd_status rmd_context_wait_transfers(rmd_context *ctx);
+rmd_status rmd_framebuffer_upload_tiles(rmd_context *ctx, const double *host_packed, double *dev, uint32_t width, uint32_t height,
+                                        const rmd_tile_rect *rects, uint32_t n_rects);
+/* Page-locked host memory (hipHostMalloc): copies to and from it run at the link's rate and asynchronously. */
+rmd_status rmd_host_alloc(rmd_context *ctx, size_t bytes, void **out_host);
+rmd_status rmd_host_free(rmd_context *ctx, void *host); /* ctx may be NULL (a block may outlive the context it was allocated through) */
 
 /*
  * The hot path.  For every pixel (x,y) of every rect in `tiles`:
@@ -273,7 +296,9 @@ typedef struct rmd_launch_info {
 	uint32_t end_black_paths; /* 1 = zero-throughput paths were ended (see RMD_RENDER_END_BLACK_PATHS)                             */
 	uint32_t has_grid;        /* 1 = the grid instantiation (wave-cooperative DDA walk) ran                                         */
 	uint32_t waves_per_workgroup; /* waves of a workgroup of the last pass (persistent form: 16 unless the LDS left room for fewer) */
-	uint32_t _pad[2];
+	uint32_t buffered;        /* 1 = the pooled (pixel, sample) hand-out + per-sample scratch + ordered sum ran (split_k > 1, or one item per
+	                             wave tile: short launches of scenes with grids), 0 = direct mode (lane = pixel, no scratch)               */
+	uint32_t _pad[1];
 } rmd_launch_info;
 rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out);
 

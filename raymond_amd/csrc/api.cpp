@@ -67,6 +67,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_MASK_BUDGET] = env_int("RMD_MASK_BUDGET");
 		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
 		ctx->tunable[RMD_TUNE_WALK_CUT] = env_int("RMD_WALK_CUT");
+		ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] = env_int("RMD_SPLIT_MIN_SAMPLES");
 		const char *form = std::getenv("RMD_LAUNCH_FORM");
 		ctx->tunable[RMD_TUNE_LAUNCH_FORM] = !form ? 0 : (std::strcmp(form, "per-item") == 0 || std::strcmp(form, "1") == 0) ? 1 : (std::strcmp(form, "persistent") == 0 || std::strcmp(form, "2") == 0) ? 2 : 0;
 #if RMD_DIAG
@@ -248,6 +249,14 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
 	if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
 	if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
+	if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+	for (auto &sl : ctx->transfer) {
+		if (sl.d_packed) (void)hipFree(sl.d_packed);
+		if (sl.d_table) (void)hipFree(sl.d_table);
+		if (sl.packed_ready) (void)hipEventDestroy(sl.packed_ready);
+		if (sl.copied) (void)hipEventDestroy(sl.copied);
+	}
+	if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -255,6 +264,106 @@ void rmd_context_destroy(rmd_context *ctx) {
 }
 
 const char *rmd_last_error(const rmd_context *ctx) { return ctx ? ctx->last_error.c_str() : tl_last_error.c_str(); }
+
+// What rmd_scene_create derives from a grid description before it uploads it (device_types.hpp: DevGrid): validated tables, the triangle
+// records, the per-cell index lists with their entries, the Heron constants.  ~50 ms of host time for the 99k-triangle benchmark mesh — a host
+// scheduler creates a scene per render_tiled call and per GPU (the counterpart of the reference's per-worker `scene.clone()`, src/trace.rs:182-185),
+// so a description that comes from a rmd_grid_build (rmd_grid_desc::built) keeps them in that object: derived once, shared by every upload.
+struct GridDerived {
+	std::vector<unsigned char> recs;
+	std::vector<rmd::CellEntry> entries;
+	std::vector<uint32_t> ids;
+	std::vector<double> aux;
+};
+static rmd_status derive_grid_tables(rmd_context *ctx, const rmd_grid_desc &g, GridDerived &out) {
+	{
+		if (!g.cells || !g.mapping_table || !g.tri_pos || !g.tri_nrm || g.n_tris == 0 ||
+		    g.n_cells != (uint64_t)g.resolution[0] * g.resolution[1] * g.resolution[2]) {
+			return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: inconsistent grid description");
+		}
+		// validate the CSR-like table so that the kernel's gathers stay in bounds
+		for (uint64_t c = 0; c < g.n_cells; c++) {
+			uint64_t off = g.cells[c];
+			if (off >= g.n_mapping || off + (uint64_t)g.mapping_table[off] >= g.n_mapping) {
+				return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table run out of range");
+			}
+			uint32_t cnt = g.mapping_table[off];
+			for (uint32_t k = 1; k <= cnt; k++)
+				if (g.mapping_table[off + k] >= g.n_tris) {
+					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: triangle index out of range in mapping_table");
+				}
+		}
+		// the kernel keeps the reference's linear cell index x + res.x*(y + z*res.z) in 32 bits
+		if ((uint64_t)g.resolution[0] * ((uint64_t)g.resolution[1] + (uint64_t)g.resolution[2] * g.resolution[2]) >= (1ull << 31) ||
+		    g.n_cells > (1ull << 31)) {
+			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: grid resolution too large for 31-bit cell indices");
+		}
+		// triangle records, per-cell lists of triangle indices and the cell entries (device_types.hpp): record = v0, edge1 = v1 - v0,
+		// edge2 = v2 - v0 (triangle.rs:16-17, same subtraction, done once); entry slot 0 = the cell's list in mapping_table order, slots 1..6 =
+		// that list without the triangles the cell at index c - delta_s lists too (the cell a walk came from: tested already, missed)
+		const uint64_t n_refs = g.n_mapping - g.n_cells;
+		if (n_refs > 0xFFFFFFFFull) {
+			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: more than 2^32-1 cell->triangle references");
+		}
+		std::vector<unsigned char> &recs = out.recs;
+		recs.assign((size_t)g.n_tris * rmd::kTriRecStride, 0);
+		for (uint64_t ti = 0; ti < g.n_tris; ti++) {
+			const double *p = g.tri_pos + (size_t)ti * 9;
+			double q[9];
+			for (int a = 0; a < 3; a++) q[a] = p[a], q[3 + a] = p[3 + a] - p[a], q[6 + a] = p[6 + a] - p[a];
+			std::memcpy(recs.data() + (size_t)ti * rmd::kTriRecStride, q, sizeof(q));
+		}
+		std::vector<rmd::CellEntry> &entries = out.entries;
+		entries.assign((size_t)g.n_cells * rmd::kEntrySlots, rmd::CellEntry{0u, 0u});
+		std::vector<uint32_t> &ids = out.ids;
+		ids.clear();
+		ids.reserve((size_t)n_refs * 3);
+		{
+			uint64_t refs_seen = 0;
+			for (uint64_t c = 0; c < g.n_cells; c++) { // slot 0: the full lists, validated against overlapping runs
+				const uint32_t off = g.cells[c], cnt = g.mapping_table[off];
+				refs_seen += cnt;
+				if (refs_seen > n_refs) { // cells sharing a run: the tables are not the builder's; refuse rather than overflow
+							return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table runs overlap");
+				}
+				entries[c * rmd::kEntrySlots] = rmd::CellEntry{(uint32_t)ids.size(), cnt};
+				ids.insert(ids.end(), g.mapping_table + off + 1, g.mapping_table + off + 1 + cnt);
+			}
+			const int64_t sx = (int64_t)g.resolution[0], sxz = (int64_t)g.resolution[0] * (int64_t)g.resolution[2]; // Q5: res.z where res.y is meant
+			const int64_t delta[7] = {0, 1, -1, sx, -sx, sxz, -sxz};
+			std::vector<uint32_t> fresh;
+			std::vector<uint64_t> listed_by((size_t)g.n_tris, ~0ull); // triangle -> the (cell, slot) pass that last saw it in a predecessor's list
+			for (uint64_t c = 0; c < g.n_cells; c++) {
+				const rmd::CellEntry full = entries[c * rmd::kEntrySlots];
+				const uint32_t *mine = g.mapping_table + g.cells[c] + 1;
+				for (uint32_t s = 1; s < rmd::kEntrySlots; s++) {
+					rmd::CellEntry &e = entries[c * rmd::kEntrySlots + s];
+					e = full;
+					if (s == 7u || full.count == 0u) continue;
+					const int64_t prev = (int64_t)c - delta[s];
+					if (prev < 0 || prev >= (int64_t)g.n_cells || prev == (int64_t)c) continue; // no such predecessor: never asked for
+					const uint32_t poff = g.cells[prev], pcnt = g.mapping_table[poff];
+					if (pcnt == 0u) continue;
+					const uint32_t *theirs = g.mapping_table + poff + 1;
+					fresh.clear();
+					const uint64_t pass = c * rmd::kEntrySlots + s;
+					for (uint32_t j = 0; j < pcnt; j++) listed_by[theirs[j]] = pass;
+					for (uint32_t k = 0; k < full.count; k++)
+						if (listed_by[mine[k]] != pass) fresh.push_back(mine[k]);
+					if (fresh.size() == full.count) continue; // nothing to leave out: shares the full list
+					e = rmd::CellEntry{(uint32_t)ids.size(), (uint32_t)fresh.size()};
+					ids.insert(ids.end(), fresh.begin(), fresh.end());
+					if (ids.size() > 0xFFFFFFFFull) {
+									return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: triangle index lists exceed 2^32 entries");
+					}
+				}
+			}
+		}
+		out.aux.assign((size_t)g.n_tris * 4, 0.0);
+		for (uint64_t ti = 0; ti < g.n_tris; ti++) rmd::triangle_aux(g.tri_pos + (size_t)ti * 9, out.aux.data() + (size_t)ti * 4);
+	}
+	return RMD_OK;
+}
 
 // (`sc`: the scene under construction, owned by the caller's frame so that an exception — std::bad_alloc from one of the host-side tables: a
 // 256^3 grid needs a gigabyte for its cell entries alone — can still release what has been uploaded)
@@ -346,97 +455,36 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 		const rmd_grid_desc &g = grids[gi];
 		rmd::DevGrid &d = hgrid[gi];
 		std::memset(&d, 0, sizeof(d));
-		if (!g.cells || !g.mapping_table || !g.tri_pos || !g.tri_nrm || g.n_tris == 0 ||
-		    g.n_cells != (uint64_t)g.resolution[0] * g.resolution[1] * g.resolution[2]) {
-			rmd_scene_destroy(sc), sc = nullptr;
-			return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: inconsistent grid description");
-		}
-		// validate the CSR-like table so that the kernel's gathers stay in bounds
-		for (uint64_t c = 0; c < g.n_cells; c++) {
-			uint64_t off = g.cells[c];
-			if (off >= g.n_mapping || off + (uint64_t)g.mapping_table[off] >= g.n_mapping) {
-				rmd_scene_destroy(sc), sc = nullptr;
-				return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table run out of range");
+		// the derived tables: from the rmd_grid_build this description came from (derived once, kept there), or made here
+		std::shared_ptr<const GridDerived> derived;
+		{
+			rmd_grid_build *gb = const_cast<rmd_grid_build *>(g.built);
+			const bool from_build = gb && gb->cells.data() == g.cells && gb->cells.size() == g.n_cells && gb->mapping.data() == g.mapping_table &&
+			                        gb->mapping.size() == g.n_mapping && gb->pos.data() == g.tri_pos && gb->nrm.data() == g.tri_nrm && gb->pos.size() == g.n_tris * 9;
+			std::unique_lock<std::mutex> lock;
+			if (from_build) {
+				lock = std::unique_lock<std::mutex>(gb->derived_mutex);
+				derived = std::static_pointer_cast<const GridDerived>(gb->derived);
 			}
-			uint32_t cnt = g.mapping_table[off];
-			for (uint32_t k = 1; k <= cnt; k++)
-				if (g.mapping_table[off + k] >= g.n_tris) {
+			if (!derived) {
+				auto fresh = std::make_shared<GridDerived>();
+				if (rmd_status st = derive_grid_tables(ctx, g, *fresh)) {
 					rmd_scene_destroy(sc), sc = nullptr;
-					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: triangle index out of range in mapping_table");
+					return st;
 				}
+				derived = fresh;
+				if (from_build) gb->derived = fresh;
+			}
 		}
+		const std::vector<unsigned char> &recs = derived->recs;
+		const std::vector<rmd::CellEntry> &entries = derived->entries;
+		const std::vector<uint32_t> &ids = derived->ids;
+		const std::vector<double> &aux = derived->aux;
 		for (int a = 0; a < 3; a++) {
 			d.bbox_min[a] = g.bbox_min[a], d.bbox_max[a] = g.bbox_max[a], d.cell_size[a] = g.cell_size[a];
 			d.res[a] = g.resolution[a];
 		}
 		d.n_cells = g.n_cells, d.n_tris = g.n_tris;
-		// the kernel keeps the reference's linear cell index x + res.x*(y + z*res.z) in 32 bits
-		if ((uint64_t)g.resolution[0] * ((uint64_t)g.resolution[1] + (uint64_t)g.resolution[2] * g.resolution[2]) >= (1ull << 31) ||
-		    g.n_cells > (1ull << 31)) {
-			rmd_scene_destroy(sc), sc = nullptr;
-			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: grid resolution too large for 31-bit cell indices");
-		}
-		// triangle records, per-cell lists of triangle indices and the cell entries (device_types.hpp): record = v0, edge1 = v1 - v0,
-		// edge2 = v2 - v0 (triangle.rs:16-17, same subtraction, done once); entry slot 0 = the cell's list in mapping_table order, slots 1..6 =
-		// that list without the triangles the cell at index c - delta_s lists too (the cell a walk came from: tested already, missed)
-		const uint64_t n_refs = g.n_mapping - g.n_cells;
-		if (n_refs > 0xFFFFFFFFull) {
-			rmd_scene_destroy(sc), sc = nullptr;
-			return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: more than 2^32-1 cell->triangle references");
-		}
-		std::vector<unsigned char> recs((size_t)g.n_tris * rmd::kTriRecStride, 0);
-		for (uint64_t ti = 0; ti < g.n_tris; ti++) {
-			const double *p = g.tri_pos + (size_t)ti * 9;
-			double q[9];
-			for (int a = 0; a < 3; a++) q[a] = p[a], q[3 + a] = p[3 + a] - p[a], q[6 + a] = p[6 + a] - p[a];
-			std::memcpy(recs.data() + (size_t)ti * rmd::kTriRecStride, q, sizeof(q));
-		}
-		std::vector<rmd::CellEntry> entries((size_t)g.n_cells * rmd::kEntrySlots);
-		std::vector<uint32_t> ids;
-		ids.reserve((size_t)n_refs * 3);
-		{
-			uint64_t refs_seen = 0;
-			for (uint64_t c = 0; c < g.n_cells; c++) { // slot 0: the full lists, validated against overlapping runs
-				const uint32_t off = g.cells[c], cnt = g.mapping_table[off];
-				refs_seen += cnt;
-				if (refs_seen > n_refs) { // cells sharing a run: the tables are not the builder's; refuse rather than overflow
-					rmd_scene_destroy(sc), sc = nullptr;
-					return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_scene_create: cells/mapping_table runs overlap");
-				}
-				entries[c * rmd::kEntrySlots] = rmd::CellEntry{(uint32_t)ids.size(), cnt};
-				ids.insert(ids.end(), g.mapping_table + off + 1, g.mapping_table + off + 1 + cnt);
-			}
-			const int64_t sx = (int64_t)g.resolution[0], sxz = (int64_t)g.resolution[0] * (int64_t)g.resolution[2]; // Q5: res.z where res.y is meant
-			const int64_t delta[7] = {0, 1, -1, sx, -sx, sxz, -sxz};
-			std::vector<uint32_t> fresh;
-			std::vector<uint64_t> listed_by((size_t)g.n_tris, ~0ull); // triangle -> the (cell, slot) pass that last saw it in a predecessor's list
-			for (uint64_t c = 0; c < g.n_cells; c++) {
-				const rmd::CellEntry full = entries[c * rmd::kEntrySlots];
-				const uint32_t *mine = g.mapping_table + g.cells[c] + 1;
-				for (uint32_t s = 1; s < rmd::kEntrySlots; s++) {
-					rmd::CellEntry &e = entries[c * rmd::kEntrySlots + s];
-					e = full;
-					if (s == 7u || full.count == 0u) continue;
-					const int64_t prev = (int64_t)c - delta[s];
-					if (prev < 0 || prev >= (int64_t)g.n_cells || prev == (int64_t)c) continue; // no such predecessor: never asked for
-					const uint32_t poff = g.cells[prev], pcnt = g.mapping_table[poff];
-					if (pcnt == 0u) continue;
-					const uint32_t *theirs = g.mapping_table + poff + 1;
-					fresh.clear();
-					const uint64_t pass = c * rmd::kEntrySlots + s;
-					for (uint32_t j = 0; j < pcnt; j++) listed_by[theirs[j]] = pass;
-					for (uint32_t k = 0; k < full.count; k++)
-						if (listed_by[mine[k]] != pass) fresh.push_back(mine[k]);
-					if (fresh.size() == full.count) continue; // nothing to leave out: shares the full list
-					e = rmd::CellEntry{(uint32_t)ids.size(), (uint32_t)fresh.size()};
-					ids.insert(ids.end(), fresh.begin(), fresh.end());
-					if (ids.size() > 0xFFFFFFFFull) {
-						rmd_scene_destroy(sc), sc = nullptr;
-						return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_scene_create: triangle index lists exceed 2^32 entries");
-					}
-				}
-			}
-		}
 		uint64_t last_nonempty = 0;
 		bool any_nonempty = false;
 		for (uint64_t c = 0; c < g.n_cells; c++)
@@ -477,8 +525,6 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 		d.tri_pos = (const double *)p;
 		RMD_SCENE_HIP(upload(g.tri_nrm, g.n_tris * 9 * sizeof(double), &p));
 		d.tri_nrm = (const double *)p;
-		std::vector<double> aux((size_t)g.n_tris * 4);
-		for (uint64_t ti = 0; ti < g.n_tris; ti++) rmd::triangle_aux(g.tri_pos + (size_t)ti * 9, aux.data() + (size_t)ti * 4);
 		RMD_SCENE_HIP(upload(aux.data(), aux.size() * sizeof(double), &p));
 		d.tri_aux = (const double *)p;
 	}
@@ -560,11 +606,17 @@ rmd_status rmd_framebuffer_upload(rmd_context *ctx, const double *host, double *
 // to the unsplit launch (tests/test_gpu_parity.py::test_sample_split_is_bit_exact).  It buys enough items to level the launch over 256 CUs
 // when wave tiles are few (an N-way shard) or very uneven (a mesh), and lanes that draw (pixel, sample) pairs from the item's pool instead
 // of idling until the tile's longest pixel is done.  RMD_TUNE_SAMPLE_SPLIT forces K.
-static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_wave_tiles, uint32_t sample_count) {
+// `buffered` (out): whether the launch runs the tiles-buffered instantiation.  A split launch (K > 1) always does; a launch too short to split
+// does too — as ONE item per wave tile — in scenes with grids (the direct instantiation of the mesh kernel is the slower one at any size: C3 at
+// 4 spp 5.6 ms direct, 4.5 ms as two items of 2 samples; progressive passes of a host scheduler are such launches) and, from kSortedMinSamples
+// samples on, in scenes without.  RMD_TUNE_SAMPLE_SPLIT = 1 still forces the direct mode (the scratch-free route).
+static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_wave_tiles, uint32_t sample_count, bool *buffered = nullptr) {
 	uint32_t k = 1;
+	bool may_buffer_unsplit = n_wave_tiles != 0 && sample_count >= (has_grid ? 1u : rmd::kSortedMinSamples);
 	if (ctx->tunable[RMD_TUNE_SAMPLE_SPLIT] > 0) {
 		k = (uint32_t)ctx->tunable[RMD_TUNE_SAMPLE_SPLIT];
 		if (k > sample_count / 4u) k = sample_count / 4u; // a forced split keeps >= 4 samples (256 pool items) per wave
+		may_buffer_unsplit = false;
 	} else if (n_wave_tiles != 0) {
 		// Mesh kernel: about 64 work items per wave slot level the tail of a launch of persistent workgroups (tools/split_sweep.py — full C3 frame:
 		// 512.8 ms at 32, 508.1 at 64 .. 128, 517.8 at 500), of at least 4 samples each.  Spheres kernel (trips sorted by role,
@@ -575,12 +627,15 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 		const uint32_t waves_per_slot = has_grid ? 64u : 24u;
 		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
-		const uint32_t min_samples = has_grid ? 4u : 64u;
+		uint32_t min_samples = has_grid ? rmd::kSplitMinSamplesGrid : 64u;
+		if (ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] > 0) min_samples = (uint32_t)std::min<int64_t>(ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES], 1 << 20);
 		if (k > sample_count / min_samples) k = sample_count / min_samples;
 	}
 	if (k > 64u) k = 64u;
 	while (k > 1u && (uint64_t)n_wave_tiles * k > 0x7FFFFFFFull) k--; // work items are indexed in 32 bits
-	return k < 2u ? 1u : k;
+	if (k < 2u) k = 1u;
+	if (buffered) *buffered = k > 1u || may_buffer_unsplit;
+	return k;
 }
 
 rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
@@ -602,7 +657,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		RMD_HIP(ctx, hipMemsetAsync(ctx->d_debug_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
 		P.debug_counters = ctx->d_debug_counters;
 	}
-	uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count);
+	bool buffered = false;
+	uint32_t split = choose_split(ctx, scene->n_grids != 0, P.n_work, P.sample_count, &buffered);
 	// default form: persistent workgroups, one per CU, whose waves draw their work items from a counter (form 1: one wave per work
 	// item — round 1's; 4.7 % slower on the benchmark mesh, 2.4 % on the spheres frame, where a workgroup launch per item cost ~100 us
 	// of a wave slot each: 152 vs 113.6 ms at 32 items per wave tile)
@@ -615,7 +671,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 	// can be had (the old one stays until a larger one exists), and when not even 8 samples fit the launch runs unsplit (one wave per
 	// wave tile, no scratch).  Every route gives the same frame bit for bit.
 	uint32_t per_pass = P.sample_count;
-	if (split > 1u) {
+	if (buffered) {
 		const size_t bytes_per_sample = (size_t)P.n_work * 64u * rmd::kSampleStride * sizeof(double);
 		size_t cap;
 		if (ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] > 0) cap = (size_t)ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] << 20;
@@ -638,7 +694,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			(void)hipGetLastError(); // the failure is handled here: it must not surface at the next launch check
 			if (e != hipErrorOutOfMemory) return rmd::fail(ctx, RMD_ERR_HIP, std::string("hipMalloc(sample scratch): ") + hipGetErrorString(e));
 			if (per_pass <= 8u) { // not even the smallest pass: render unsplit
-				split = 1u, per_pass = P.sample_count;
+				split = 1u, buffered = false, per_pass = P.sample_count;
 				break;
 			}
 			per_pass = per_pass / 2u < 8u ? 8u : per_pass / 2u;
@@ -652,6 +708,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		Q.sample_begin = settings->sample_begin + (uint32_t)done;
 		Q.sample_count = settings->sample_count - done < per_pass ? (uint32_t)(settings->sample_count - done) : per_pass;
 		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
+		Q.buffered = buffered ? 1u : 0u;
 		Q.sample_buf = ctx->d_sample_buf;
 		// (a launch with fewer work items than the device has wave slots spreads better as one wave per item)
 		const bool persistent_pass = persistent && ((uint64_t)P.n_work * Q.split_k >= ctx->wave_slots || ctx->tunable[RMD_TUNE_LAUNCH_FORM] == 2);
@@ -662,7 +719,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		// spheres kernel: the wave that finishes a wave tile last adds the tile's samples to the pixels itself (no second kernel: 120.3 ->
 		// 117.0 ms per C2 frame).  Mesh scenes keep sum_kernel: their kernel waits on memory a third of the time, and the sum's 33 GB of
 		// streaming reads in between cost it more (491.4 vs 487.3 ms on C3) than the separate kernel's 5.5 ms
-		if (Q.split_k > 1u && scene->n_grids == 0) {
+		if (buffered && scene->n_grids == 0) {
 			if (ctx->tile_done_words < P.n_work) {
 				if (ctx->d_tile_done) RMD_HIP(ctx, hipFree(ctx->d_tile_done));
 				ctx->d_tile_done = nullptr, ctx->tile_done_words = 0;
@@ -674,7 +731,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		}
 		rmd::LaunchShape shape;
 		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent_pass ? ctx->n_cus : 0u, &shape));
-		ctx->last_launch.passes++, ctx->last_launch.split_k = Q.split_k;
+		ctx->last_launch.passes++, ctx->last_launch.split_k = Q.split_k, ctx->last_launch.buffered = Q.buffered;
 		ctx->last_launch.persistent = shape.persistent, ctx->last_launch.waves_per_workgroup = shape.waves_per_wg; // the form it was launched in, not the one asked for
 		if (settings->sample_count == 0) break;
 	}
@@ -740,6 +797,117 @@ rmd_status rmd_render_tiles_host(rmd_context *ctx, const rmd_scene *scene, const
 	if (!s) s = rmd_framebuffer_download(ctx, dev, accum_host, n);
 	(void)hipFree(dev);
 	return s;
+}
+
+// ---------------------------------------------------------------- tile rectangles <-> packed host buffers
+namespace {
+// Checks the rects, builds the table {rect, first pixel} and makes slot `sl`'s device buffers large enough.  Returns the packed pixel count.
+rmd_status prepare_transfer(rmd_context *ctx, rmd_context::TransferSlot &sl, uint32_t W, uint32_t H, const rmd_tile_rect *rects, uint32_t n_rects, uint64_t &n_pixels) {
+	n_pixels = 0;
+	sl.h_table.resize((size_t)n_rects * (sizeof(rmd_tile_rect) + sizeof(uint64_t)));
+	rmd_tile_rect *hr = reinterpret_cast<rmd_tile_rect *>(sl.h_table.data());
+	uint64_t *hf = reinterpret_cast<uint64_t *>(sl.h_table.data() + (size_t)n_rects * sizeof(rmd_tile_rect));
+	for (uint32_t i = 0; i < n_rects; i++) {
+		const rmd_tile_rect &r = rects[i];
+		if ((uint64_t)r.left + r.width > W || (uint64_t)r.top + r.height > H)
+			return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "tile transfer: tile rectangle outside the framebuffer");
+		hr[i] = r, hf[i] = n_pixels;
+		n_pixels += (uint64_t)r.width * r.height;
+	}
+	const size_t need = (size_t)n_pixels * 3 * sizeof(double);
+	if (need > sl.packed_bytes) {
+		if (sl.d_packed) RMD_HIP(ctx, hipFree(sl.d_packed));
+		sl.d_packed = nullptr, sl.packed_bytes = 0;
+		RMD_HIP(ctx, hipMalloc((void **)&sl.d_packed, need));
+		sl.packed_bytes = need;
+	}
+	if (sl.h_table.size() > sl.table_bytes) {
+		if (sl.d_table) RMD_HIP(ctx, hipFree(sl.d_table));
+		sl.d_table = nullptr, sl.table_bytes = 0;
+		RMD_HIP(ctx, hipMalloc(&sl.d_table, sl.h_table.size()));
+		sl.table_bytes = sl.h_table.size();
+	}
+	if (!sl.packed_ready) RMD_HIP(ctx, hipEventCreateWithFlags(&sl.packed_ready, hipEventDisableTiming));
+	if (!sl.copied) RMD_HIP(ctx, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+	if (!ctx->copy_stream) RMD_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+	return RMD_OK;
+}
+rmd_status wait_slot(rmd_context *ctx, rmd_context::TransferSlot &sl) {
+	if (sl.in_flight) {
+		RMD_HIP(ctx, hipEventSynchronize(sl.copied));
+		sl.in_flight = false;
+	}
+	return RMD_OK;
+}
+} // namespace
+
+rmd_status rmd_framebuffer_download_tiles_async(rmd_context *ctx, const double *dev, uint32_t width, uint32_t height, const rmd_tile_rect *rects,
+                                                uint32_t n_rects, double *host_packed) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!dev || !host_packed || (n_rects && !rects) || width == 0 || height == 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_download_tiles: bad argument");
+	if (n_rects == 0) return RMD_OK;
+	rmd_context::TransferSlot &sl = ctx->transfer[ctx->next_transfer];
+	ctx->next_transfer ^= 1u;
+	if (rmd_status s = wait_slot(ctx, sl)) return s; // a third download waits for the first
+	uint64_t n_pixels = 0;
+	if (rmd_status s = prepare_transfer(ctx, sl, width, height, rects, n_rects, n_pixels)) return s;
+	const rmd_tile_rect *d_rects = reinterpret_cast<const rmd_tile_rect *>(sl.d_table);
+	const uint64_t *d_first = reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(sl.d_table) + (size_t)n_rects * sizeof(rmd_tile_rect));
+	// main stream: table, pack (behind the renders enqueued before); copy stream: the download (renders enqueued after this overlap it)
+	RMD_HIP(ctx, hipMemcpyAsync(sl.d_table, sl.h_table.data(), sl.h_table.size(), hipMemcpyHostToDevice, ctx->stream));
+	RMD_HIP(ctx, rmd::launch_tile_copy(ctx->stream, true, const_cast<double *>(dev), sl.d_packed, d_rects, d_first, n_rects, width));
+	RMD_HIP(ctx, hipEventRecord(sl.packed_ready, ctx->stream));
+	RMD_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, sl.packed_ready, 0));
+	RMD_HIP(ctx, hipMemcpyAsync(host_packed, sl.d_packed, (size_t)n_pixels * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+	RMD_HIP(ctx, hipEventRecord(sl.copied, ctx->copy_stream));
+	sl.in_flight = true;
+	return RMD_OK;
+}
+
+rmd_status rmd_context_wait_transfers(rmd_context *ctx) {
+	if (rmd_status s = bind(ctx)) return s;
+	for (auto &sl : ctx->transfer)
+		if (rmd_status s = wait_slot(ctx, sl)) return s;
+	return rmd::check_fault(ctx); // the tiles came from launches that have completed by now
+}
+
+rmd_status rmd_framebuffer_download_tiles(rmd_context *ctx, const double *dev, uint32_t width, uint32_t height, const rmd_tile_rect *rects,
+                                          uint32_t n_rects, double *host_packed) {
+	if (rmd_status s = rmd_framebuffer_download_tiles_async(ctx, dev, width, height, rects, n_rects, host_packed)) return s;
+	return rmd_context_wait_transfers(ctx);
+}
+
+rmd_status rmd_framebuffer_upload_tiles(rmd_context *ctx, const double *host_packed, double *dev, uint32_t width, uint32_t height,
+                                        const rmd_tile_rect *rects, uint32_t n_rects) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!dev || !host_packed || (n_rects && !rects) || width == 0 || height == 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_upload_tiles: bad argument");
+	if (n_rects == 0) return RMD_OK;
+	rmd_context::TransferSlot &sl = ctx->transfer[ctx->next_transfer];
+	ctx->next_transfer ^= 1u;
+	if (rmd_status s = wait_slot(ctx, sl)) return s;
+	uint64_t n_pixels = 0;
+	if (rmd_status s = prepare_transfer(ctx, sl, width, height, rects, n_rects, n_pixels)) return s;
+	const rmd_tile_rect *d_rects = reinterpret_cast<const rmd_tile_rect *>(sl.d_table);
+	const uint64_t *d_first = reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(sl.d_table) + (size_t)n_rects * sizeof(rmd_tile_rect));
+	RMD_HIP(ctx, hipMemcpyAsync(sl.d_table, sl.h_table.data(), sl.h_table.size(), hipMemcpyHostToDevice, ctx->stream));
+	RMD_HIP(ctx, hipMemcpyAsync(sl.d_packed, host_packed, (size_t)n_pixels * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	RMD_HIP(ctx, rmd::launch_tile_copy(ctx->stream, false, dev, sl.d_packed, d_rects, d_first, n_rects, width));
+	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the caller's buffer and the table are free again
+	return RMD_OK;
+}
+
+rmd_status rmd_host_alloc(rmd_context *ctx, size_t bytes, void **out_host) {
+	if (rmd_status s = bind(ctx)) return s;
+	if (!out_host || bytes == 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_host_alloc: bad argument");
+	*out_host = nullptr;
+	RMD_HIP(ctx, hipHostMalloc(out_host, bytes, hipHostMallocDefault));
+	return RMD_OK;
+}
+rmd_status rmd_host_free(rmd_context *ctx, void *host) { // (ctx may be NULL: a block may outlive the context it was allocated through)
+	if (ctx)
+		if (rmd_status s = bind(ctx)) return s;
+	if (host) RMD_HIP(ctx, hipHostFree(host));
+	return RMD_OK;
 }
 
 rmd_status rmd_last_kernel_ms(rmd_context *ctx, float *out_ms) {

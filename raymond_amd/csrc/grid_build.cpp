@@ -148,6 +148,7 @@ extern "C" rmd_status rmd_grid_build_describe(const rmd_grid_build *g, rmd_grid_
 	d->cells = g->cells.data(), d->n_cells = g->cells.size();
 	d->mapping_table = g->mapping.data(), d->n_mapping = g->mapping.size();
 	d->tri_pos = g->pos.data(), d->tri_nrm = g->nrm.data(), d->n_tris = g->pos.size() / 9;
+	d->built = g; // rmd_scene_create keeps what it derives from these arrays in the build (valid until rmd_grid_build_destroy, like the pointers above)
 	return RMD_OK;
 }
 

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +43,19 @@ struct rmd_context {
 	// fault words (device_types.hpp: kFault*): pinned host memory mapped into the device's address space.  A wave whose loop runs past its bound
 	// writes here; the host looks after every wait for the stream (api.cpp: check_fault) — a plain host load, no copy
 	uint32_t *h_fault = nullptr, *d_fault = nullptr;
+	// tile transfers (rmd_framebuffer_{download,upload}_tiles): two staging slots — packed pixels, rect table, prefix table on the device — so that a
+	// second download can be packed while the first is still being copied; the copy stream; per slot the event its copy ends with
+	struct TransferSlot {
+		double *d_packed = nullptr;
+		size_t packed_bytes = 0;
+		void *d_table = nullptr; // n_rects x (rmd_tile_rect, uint64 first)
+		size_t table_bytes = 0;
+		hipEvent_t packed_ready = nullptr, copied = nullptr;
+		bool in_flight = false;
+		std::vector<unsigned char> h_table; // the host copy of the table stays alive until its upload has completed
+	} transfer[2];
+	uint32_t next_transfer = 0;
+	hipStream_t copy_stream = nullptr;
 	// Tunables (include/raymond_hip.h: rmd_context_set_tunable).  Defaults come from the environment, read ONCE when the
 	// context is created; none of them changes a result.
 	int64_t tunable[RMD_TUNE_COUNT] = {};
@@ -66,6 +81,9 @@ struct rmd_grid_build {
 	uint32_t res[3];
 	std::vector<uint32_t> cells, mapping;
 	std::vector<double> pos, nrm;
+	// what rmd_scene_create derives from these arrays (api.cpp: GridDerived), kept for the next upload of the same grid
+	std::shared_ptr<void> derived;
+	std::mutex derived_mutex;
 };
 
 namespace rmd {

@@ -71,6 +71,30 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const double *__restrict__
 	if (flag) flagged[atomicAdd(n_flagged, 1u)] = (uint32_t)i; // the list has room for every pixel
 }
 
+// ---------------------------------------------------------------- tile rectangles <-> a packed buffer (rmd_framebuffer_{download,upload}_tiles)
+// One workgroup per rectangle; rect i's pixels row-major at packed + first[i] * 3 — the layout of core::tile::Tile.data (core/src/tile.rs:13).
+// Every access is 24 contiguous bytes per lane, a row of the rectangle (<= 32 pixels = 768 bytes) contiguous on both sides.
+template <bool TO_PACKED>
+__global__ __launch_bounds__(256) void tile_copy_kernel(double *__restrict__ frame, double *__restrict__ packed, const rmd_tile_rect *__restrict__ rects,
+                                                         const uint64_t *__restrict__ first, uint32_t W) {
+	const rmd_tile_rect r = rects[blockIdx.x];
+	const uint64_t base = first[blockIdx.x];
+	const uint32_t n = r.width * r.height;
+	for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+		const uint32_t x = i % r.width, y = i / r.width;
+		double *f = frame + ((size_t)(r.left + x) + (size_t)(r.top + y) * W) * 3, *p = packed + (base + i) * 3;
+		if (TO_PACKED) p[0] = f[0], p[1] = f[1], p[2] = f[2];
+		else f[0] = p[0], f[1] = p[1], f[2] = p[2];
+	}
+}
+hipError_t launch_tile_copy(hipStream_t stream, bool to_packed, double *frame, double *packed, const rmd_tile_rect *rects, const uint64_t *first,
+                            uint32_t n_rects, uint32_t W) {
+	if (n_rects == 0) return hipSuccess;
+	if (to_packed) hipLaunchKernelGGL(tile_copy_kernel<true>, dim3(n_rects), dim3(256), 0, stream, frame, packed, rects, first, W);
+	else hipLaunchKernelGGL(tile_copy_kernel<false>, dim3(n_rects), dim3(256), 0, stream, frame, packed, rects, first, W);
+	return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers
 size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg) {
 	// a scene has grids exactly when it has mask words reserved (an all-empty grid still reserves some)
@@ -90,8 +114,8 @@ uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total) {
 hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                                const WaveTile *wave_tiles, double *accum, uint32_t n_cus, LaunchShape *shape) {
 	if (P.n_work == 0) return hipSuccess;
-	const uint32_t n_waves = P.n_work * (P.split_k > 1u ? P.split_k : 1u);
-	const bool buffered = P.split_k > 1u;
+	const bool buffered = P.buffered != 0u;
+	const uint32_t n_waves = P.n_work * (buffered ? P.split_k : 1u);
 	hipError_t e;
 	if (P.n_grids) e = buffered ? launch_render<kModeTilesBuffered, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus, shape)
 	                            : launch_render<kModeTiles, true>(stream, P, objs, grids, wave_tiles, n_waves, accum, nullptr, nullptr, n_cus, shape);

@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "../../include/raymond_hip.h"
 #include "device_types.hpp"
 
 // entries per lane in the list-mode path record: one per trace() depth, bounce_limit <= 16
@@ -41,6 +42,17 @@ constexpr size_t kMaskBudgetBytes = 48u * 1024u;
 constexpr uint32_t kSampleStride = 4;
 // walk batching (kernels.hip): lanes of a wave that must be waiting for a grid walk before one is run
 constexpr uint32_t kWalkBatchDefault = 32;
+// fewest samples per pixel a work item of a split launch of a grid scene may hold (api.cpp: choose_split; RMD_TUNE_SPLIT_MIN_SAMPLES overrides)
+#ifndef RMD_SPLIT_MIN_SAMPLES_GRID
+#define RMD_SPLIT_MIN_SAMPLES_GRID 4
+#endif
+constexpr uint32_t kSplitMinSamplesGrid = RMD_SPLIT_MIN_SAMPLES_GRID;
+// scenes without grids: fewest samples per pixel a launch that is too short to split runs as ONE buffered item per wave tile (role-sorted trips)
+// instead of in direct mode (api.cpp: choose_split)
+#ifndef RMD_SORTED_MIN_SAMPLES
+#define RMD_SORTED_MIN_SAMPLES 128
+#endif
+constexpr uint32_t kSortedMinSamples = RMD_SORTED_MIN_SAMPLES;
 // walks put aside (grid_walk.hpp: cut_lanes): a walk call leaves its last K walkers to the wave's next call
 constexpr uint32_t kWalkCutDefault = 4;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
@@ -84,6 +96,9 @@ hipError_t launch_render_tiles(hipStream_t stream, const RenderParams &P, const 
                                const WaveTile *wave_tiles, double *accum, uint32_t n_cus = 0, LaunchShape *shape = nullptr);
 hipError_t launch_render_list(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids,
                               const ListWork *list, double *rgb_out, int32_t *path_obj, uint32_t *path_sub);
+// tile rectangles of a frame <-> a packed buffer (kernels.hip: tile_copy_kernel); `first[i]` = pixels in front of rect i
+hipError_t launch_tile_copy(hipStream_t stream, bool to_packed, double *frame, double *packed, const rmd_tile_rect *rects, const uint64_t *first,
+                            uint32_t n_rects, uint32_t W);
 // pixel += the per-sample radiance of a split launch, in sample order (kernels.hip: sum_kernel)
 hipError_t launch_sum(hipStream_t stream, const RenderParams &P, const WaveTile *wave_tiles, double *accum);
 // |255 * tm - k| below this flags a pixel for the host's libm (kernels.hip: tonemap_kernel); device exp / pow are good to ~1e-12 there

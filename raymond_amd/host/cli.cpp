@@ -7,6 +7,8 @@
 //   raymond_cli tiles W H TW TH           tile generation order of render_tiled, one "left top width height" per line
 //   raymond_cli project in.json dump|json Project::load (core/src/project.rs): flattened scene, or the re-serialised JSON
 //   raymond_cli tilemsg W H               a TileFinished message in the wire form of server/src/protocol.rs
+//   raymond_cli hostapi <spheres|dragon[:n]> W H SPP BOUNCES SPI [--end-black-paths 1]
+//                                         what a drop-in caller gets: one JSON line with the wall time of render_tiled -> last TileFinished
 //   (render also accepts `project:in.json` as its scene)
 #include <chrono>
 #include <cstdio>
@@ -19,6 +21,34 @@
 #include "raymond.hpp"
 
 using namespace raymond;
+
+// A consumer of a progressive render: every message through poll() (src/trace.rs:115-117) as it arrives — TileProgressed snapshots are counted,
+// TileFinished tiles are assembled into the image as await() would (:93-99).  (await() itself stops collecting at the first message that is not
+// TileFinished, :101-103: with snapshots of several workers in the channel it is only safe once they have been drained.)
+static std::vector<Vector3> consume(TaskHandle &handle, const Settings &st, size_t &progressed) {
+	const size_t W = st.camera_settings.backbuffer_width, H = st.camera_settings.backbuffer_height;
+	std::vector<Vector3> image(W * H, Vector3{0, 0, 0});
+	for (;;) {
+		const bool done = handle.finished(); // read BEFORE the channel is drained: nothing is sent after the last worker has left
+		while (std::optional<Message> m = handle.poll()) {
+			if (m->kind == Message::TileProgressed) {
+				progressed++;
+				continue;
+			}
+			const Tile &t = m->tile;
+			for (size_t y = 0; y < t.height; y++)
+				for (size_t x = 0; x < t.width; x++) {
+					Vector3 v = t.data[x + y * t.width];
+					for (double &c : v) c /= (double)t.sample_count; // :95
+					image[x + t.left + (y + t.top) * W] = v;
+				}
+		}
+		if (done) break;
+		std::this_thread::sleep_for(std::chrono::microseconds(200));
+	}
+	handle.await(); // joins nothing new: every worker has left; rethrows a worker's error
+	return image;
+}
 
 static void dump_mesh(const Mesh &m, const std::string &path) {
 	std::ofstream f(path, std::ios::binary);
@@ -75,6 +105,59 @@ int main(int argc, char **argv) {
 				std::printf("%u %u %u %u\n", t.left, t.top, t.width, t.height);
 			return 0;
 		}
+		if (argc >= 8 && !std::strcmp(argv[1], "hostapi")) {
+			// The measurement bench.py's `host_api` block reports: the scene is built first (as cli_old does, main.rs:45-127), a tiny untimed render
+			// initialises the process's HIP runtime, then ONE render_tiled call is timed from the call to the last TileFinished message, the
+			// TileProgressed snapshots handed to a callback as they arrive (src/trace.rs:119-134).
+			std::string what = argv[2];
+			Settings st;
+			st.camera_settings.backbuffer_width = std::atoi(argv[3]), st.camera_settings.backbuffer_height = std::atoi(argv[4]);
+			st.camera_settings.fov_vert = 55.0, st.camera_settings.focal_length = 2.5;
+			st.sample_count = std::atoi(argv[5]), st.bounce_limit = std::atoi(argv[6]), st.samples_per_iteration = std::atoi(argv[7]);
+			st.tile_size = {32, 32};
+			for (int i = 8; i + 1 < argc; i += 2)
+				if (!std::strcmp(argv[i], "--end-black-paths")) st.end_black_paths = std::atoi(argv[i + 1]) != 0;
+			Scene scene = what == "spheres" ? reflective_spheres() : gold_dragon_standin(what.size() > 7 ? std::atoi(what.c_str() + 7) : 91);
+			{
+				Settings warm = st;
+				warm.camera_settings.backbuffer_width = warm.camera_settings.backbuffer_height = 64, warm.sample_count = 1, warm.samples_per_iteration = 0;
+				render_tiled(reflective_spheres(), warm).await();
+			}
+			const int reps = 3;
+			double best = 1e30, best_setup = 0.0, best_await = 0.0;
+			size_t progressed = 0, finished_tiles = 0;
+			double checksum = 0.0;
+			for (int rep = 0; rep < reps; rep++) {
+				progressed = 0;
+				const auto t0 = std::chrono::steady_clock::now();
+				TaskHandle handle = render_tiled(scene, st);
+				// wall: call -> the last TileFinished message has been sent (the last worker has left); await: ... -> the image is assembled (:93-99)
+				double secs = 0.0;
+				std::vector<Vector3> image;
+				if (st.samples_per_iteration) {
+					image = consume(handle, st, progressed);
+					secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+				} else {
+					while (!handle.finished()) std::this_thread::sleep_for(std::chrono::microseconds(100));
+					secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+					image = handle.await();
+				}
+				const double secs_await = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+				if (secs < best) best = secs, best_setup = handle.setup_seconds(), best_await = secs_await;
+				checksum = 0.0;
+				for (const Vector3 &v : image)
+					for (double c : v)
+						if (c == c) checksum += c;
+				finished_tiles = generate_tiles(st.camera_settings.backbuffer_width, st.camera_settings.backbuffer_height, st.tile_size).size();
+			}
+			const double n = (double)st.camera_settings.backbuffer_width * st.camera_settings.backbuffer_height * st.sample_count;
+			std::printf("{\"scene\": \"%s\", \"width\": %zu, \"height\": %zu, \"spp\": %zu, \"bounces\": %zu, \"samples_per_iteration\": %zu, \"wall_ms\": %.3f, "
+			            "\"setup_ms\": %.3f, \"image_assembled_ms\": %.3f, \"msamples_per_s\": %.2f, \"msamples_per_s_after_setup\": %.2f, \"tile_progressed_messages\": %zu, \"tiles\": %zu, "
+			            "\"mean_radiance_sum\": %.17g, \"runs\": %d}\n",
+			            what.c_str(), st.camera_settings.backbuffer_width, st.camera_settings.backbuffer_height, st.sample_count, st.bounce_limit, st.samples_per_iteration,
+			            best * 1e3, best_setup * 1e3, best_await * 1e3, n / best / 1e6, n / (best - best_setup) / 1e6, progressed, finished_tiles, checksum, reps);
+			return 0;
+		}
 		if (argc >= 8 && !std::strcmp(argv[1], "render")) {
 			const auto t0 = std::chrono::steady_clock::now(); // cli_old/src/main.rs:36
 			std::string what = argv[2], raw;
@@ -99,18 +182,8 @@ int main(int argc, char **argv) {
 			else throw Error(RMD_ERR_INVALID_ARGUMENT, "unknown scene " + what);
 			TaskHandle handle = render_tiled(scene, st); // :152
 			size_t progressed = 0;
-			handle.set_callback([&](const Tile &) { progressed++; });
-			std::vector<Vector3> image;
-			if (st.samples_per_iteration) {
-				// progressive mode: hand the TileProgressed snapshots to the callback as they arrive; await() itself
-				// stops collecting at the first message that is not TileFinished (src/trace.rs:101-103)
-				while (!handle.finished()) {
-					handle.async_await();
-					std::this_thread::sleep_for(std::chrono::milliseconds(5));
-				}
-				handle.async_await();
-			}
-			image = handle.await(); // :153
+			// progressive mode: every message is taken as it arrives (consume); else await() (:153)
+			std::vector<Vector3> image = st.samples_per_iteration ? consume(handle, st, progressed) : handle.await();
 			const size_t W = st.camera_settings.backbuffer_width, H = st.camera_settings.backbuffer_height;
 			write_ppm(argv[7], tone_map(image), W, H); // :161-197
 			if (!raw.empty()) {

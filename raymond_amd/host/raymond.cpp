@@ -3,8 +3,10 @@
 #include "raymond.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -111,6 +113,7 @@ struct TaskHandle::Shared {
 	size_t alive = 0;            // alive_thread_count (:175)
 	size_t in_flight = 0;        // tiles popped by a worker and not yet finished or re-queued
 	std::string error;
+	double setup_s = 0.0;        // measurement: the longest a worker took to get ready (context, scene upload, framebuffer)
 };
 
 namespace {
@@ -143,28 +146,85 @@ void flatten(const Scene &scene, std::vector<rmd_object> &objs, std::vector<rmd_
 	}
 }
 
-// One worker = one GPU.  Pops a batch of tiles, adds `step` samples to each with ONE rmd_render_tiles call, then
-// reports them finished or re-queues them (src/trace.rs:188-221).
-void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene, Settings st, size_t batch) {
+// Page-locked blocks for the downloads, recycled: a block goes back to the pool when the last tile (message) that views it is dropped.
+struct BlockPool : std::enable_shared_from_this<BlockPool> {
+	static std::shared_ptr<BlockPool> shared() {
+		static std::shared_ptr<BlockPool> pool = std::make_shared<BlockPool>();
+		return pool;
+	}
+	std::mutex m;
+	std::vector<std::pair<void *, size_t>> free_blocks;
+	// (the blocks of the process-wide pool are left to the operating system at exit: the HIP runtime may be gone by then)
+	std::shared_ptr<void> get(rmd_context *ctx, size_t bytes) {
+		void *p = nullptr;
+		size_t have = 0;
+		{
+			std::lock_guard<std::mutex> lock(m);
+			for (size_t i = 0; i < free_blocks.size(); i++)
+				if (free_blocks[i].second >= bytes) {
+					p = free_blocks[i].first, have = free_blocks[i].second;
+					free_blocks.erase(free_blocks.begin() + (long)i);
+					break;
+				}
+		}
+		if (!p) {
+			check(rmd_host_alloc(ctx, bytes, &p), ctx, "rmd_host_alloc");
+			have = bytes;
+		}
+		std::shared_ptr<BlockPool> self = shared_from_this();
+		return std::shared_ptr<void>(p, [self, have](void *q) {
+			std::lock_guard<std::mutex> lock(self->m);
+			if (self->free_blocks.size() < 4) self->free_blocks.emplace_back(q, have);
+			else rmd_host_free(nullptr, q);
+		});
+	}
+};
+
+// One worker = one GPU.  Pops a batch of tiles, adds `step` samples to each with ONE rmd_render_tiles call per sample count, then reports them
+// finished or re-queues them (src/trace.rs:188-221).  The tiles' sums stay in this GPU's framebuffer; only what a message carries is downloaded,
+// on the copy stream, while the next batch renders (the messages of batch k are sent while batch k + 1 runs).
+void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, int me, size_t workers, Scene scene, Settings st, size_t batch) {
 	rmd_context *ctx = nullptr;
 	rmd_scene *dscene = nullptr;
 	double *fb = nullptr;
 	const size_t W = st.camera_settings.backbuffer_width, H = st.camera_settings.backbuffer_height;
+	// a batch whose download is on its way: the tiles that become messages, in message order
+	struct Pending {
+		std::vector<Message> messages;
+		std::vector<Tile> requeue; // (several workers: tiles that go back to the queue with their sums in RAM)
+		size_t taken = 0;          // tiles of the batch that were neither finished nor re-queued at once (they leave `in_flight` now)
+	};
+	std::optional<Pending> pending;
+	auto flush = [&]() { // the previous batch's download has to arrive before its messages can be sent
+		if (!pending) return;
+		check(rmd_context_wait_transfers(ctx), ctx, "rmd_context_wait_transfers");
+		std::lock_guard<std::mutex> lock(sh->m);
+		for (Message &m : pending->messages) sh->channel.push_back(std::move(m));
+		for (Tile &t : pending->requeue) sh->queue.push_back(std::move(t));
+		sh->in_flight -= pending->taken;
+		pending.reset();
+		sh->cv.notify_all();
+	};
 	try {
+		const auto t_setup = std::chrono::steady_clock::now();
 		check(rmd_context_create(device, &ctx), nullptr, "rmd_context_create");
 		std::vector<rmd_object> objs;
 		std::vector<rmd_grid_desc> grids;
 		flatten(scene, objs, grids);
 		check(rmd_scene_create(ctx, objs.data(), (uint32_t)objs.size(), grids.data(), (uint32_t)grids.size(), &dscene), ctx, "rmd_scene_create");
-		check(rmd_framebuffer_alloc(ctx, (uint32_t)W, (uint32_t)H, &fb), ctx, "rmd_framebuffer_alloc");
+		check(rmd_framebuffer_alloc(ctx, (uint32_t)W, (uint32_t)H, &fb), ctx, "rmd_framebuffer_alloc"); // zeroed: a fresh tile's sums
+		{
+			std::lock_guard<std::mutex> lock(sh->m);
+			sh->setup_s = std::max(sh->setup_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup).count());
+		}
 		rmd_camera cam;
 		std::memset(&cam, 0, sizeof(cam));
 		cam.backbuffer_width = (uint32_t)W, cam.backbuffer_height = (uint32_t)H, cam.fov_vert = st.camera_settings.fov_vert;
 		for (int a = 0; a < 3; a++) cam.position[a] = st.camera_settings.transform.position[a];
 		cam.focal_length = st.camera_settings.focal_length, cam.aperture_radius = st.camera_settings.aperture_radius;
 		const uint32_t flags = (st.use_dof ? RMD_RENDER_DOF : 0u) | (st.end_black_paths ? RMD_RENDER_END_BLACK_PATHS : 0u); // 0 = the reference's loop: pinhole (:199), every sample identical
-		std::vector<double> host(W * H * 3);
 		const size_t step = st.samples_per_iteration ? st.samples_per_iteration : st.sample_count;
+		std::shared_ptr<BlockPool> pool = BlockPool::shared(); // process-wide: page-locking 50 MB costs about as much as moving them
 		for (;;) {
 			std::vector<Tile> mine;
 			{
@@ -173,6 +233,11 @@ void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene
 				// for the next progressive pass — would collapse the pool to one GPU, so a worker leaves only when no tile is
 				// queued AND none is in flight.
 				std::unique_lock<std::mutex> lock(sh->m);
+				if (sh->queue.empty() && pending) { // nothing to start: send what is pending (it may re-queue tiles or end the render)
+					lock.unlock();
+					flush();
+					lock.lock();
+				}
 				sh->cv.wait(lock, [&] { return !sh->queue.empty() || sh->in_flight == 0 || !sh->error.empty(); });
 				while (sh->error.empty() && !sh->queue.empty() && mine.size() < batch) {
 					mine.push_back(std::move(sh->queue.front()));
@@ -181,47 +246,91 @@ void worker_main(std::shared_ptr<TaskHandle::Shared> sh, int device, Scene scene
 				sh->in_flight += mine.size();
 			}
 			if (mine.empty()) break;
-			// tiles of one batch may be at different sample counts; group by sample_count
+			// tiles that arrive with their sums in RAM (another GPU rendered their earlier passes): into this GPU's framebuffer
+			{
+				std::vector<rmd_tile_rect> rects;
+				std::vector<double> packed;
+				for (Tile &t : mine)
+					if (t.resident != me && t.sample_count != 0) {
+						rects.push_back(rmd_tile_rect{(uint32_t)t.left, (uint32_t)t.top, (uint32_t)t.width, (uint32_t)t.height});
+						const double *src = reinterpret_cast<const double *>(t.data.data());
+						packed.insert(packed.end(), src, src + t.data.size() * 3);
+					}
+				if (!rects.empty()) check(rmd_framebuffer_upload_tiles(ctx, packed.data(), fb, (uint32_t)W, (uint32_t)H, rects.data(), (uint32_t)rects.size()), ctx, "rmd_framebuffer_upload_tiles");
+			}
+			// tiles of one batch may be at different sample counts: one launch per count (enqueued, not waited for)
 			std::map<size_t, std::vector<size_t>> by_count;
 			for (size_t i = 0; i < mine.size(); i++) by_count[mine[i].sample_count].push_back(i);
 			for (auto &grp : by_count) {
 				const size_t begin = grp.first, n = std::min(step, st.sample_count - begin);
-				std::fill(host.begin(), host.end(), 0.0);
 				std::vector<rmd_tile_rect> rects;
-				for (size_t i : grp.second) {
-					const Tile &t = mine[i];
-					rects.push_back(rmd_tile_rect{(uint32_t)t.left, (uint32_t)t.top, (uint32_t)t.width, (uint32_t)t.height});
-					for (size_t y = 0; y < t.height; y++)
-						for (size_t x = 0; x < t.width; x++)
-							std::memcpy(&host[((t.left + x) + (t.top + y) * W) * 3], t.data[x + y * t.width].data(), 24);
-				}
-				check(rmd_framebuffer_upload(ctx, host.data(), fb, host.size()), ctx, "rmd_framebuffer_upload");
+				for (size_t i : grp.second) rects.push_back(rmd_tile_rect{(uint32_t)mine[i].left, (uint32_t)mine[i].top, (uint32_t)mine[i].width, (uint32_t)mine[i].height});
 				rmd_settings rs;
 				std::memset(&rs, 0, sizeof(rs));
 				rs.bounce_limit = (uint32_t)st.bounce_limit, rs.sample_begin = (uint32_t)begin, rs.sample_count = (uint32_t)n, rs.seed = st.seed, rs.flags = flags;
-				check(rmd_render_tiles(ctx, dscene, &cam, &rs, rects.data(), (uint32_t)rects.size(), fb), ctx, "rmd_render_tiles");
-				check(rmd_framebuffer_download(ctx, fb, host.data(), host.size()), ctx, "rmd_framebuffer_download");
-				for (size_t i : grp.second) {
-					Tile &t = mine[i];
-					for (size_t y = 0; y < t.height; y++)
-						for (size_t x = 0; x < t.width; x++)
-							std::memcpy(t.data[x + y * t.width].data(), &host[((t.left + x) + (t.top + y) * W) * 3], 24);
-					t.sample_count += n; // :207
+				check(rmd_render_tiles_async(ctx, dscene, &cam, &rs, rects.data(), (uint32_t)rects.size(), fb), ctx, "rmd_render_tiles");
+				for (size_t i : grp.second) mine[i].sample_count += n, mine[i].resident = me, mine[i].data = TileData(); // :207 — the sums are on this GPU now
+			}
+			// the previous batch's messages go out while this batch renders
+			flush();
+			// what of this batch has to come to the host: finished tiles (:211-212), progress snapshots (:217-219), and — with several GPUs — every
+			// tile that goes back to the shared queue (another GPU may take it next)
+			Pending next;
+			std::vector<rmd_tile_rect> rects;
+			std::vector<size_t> want;
+			std::vector<Tile> resident_requeue;
+			size_t pixels = 0;
+			for (size_t i = 0; i < mine.size(); i++) {
+				Tile &t = mine[i];
+				const bool finished = t.sample_count == st.sample_count;
+				const bool progressed = !finished && st.samples_per_iteration != 0 && t.sample_count % st.samples_per_iteration == 0;
+				if (finished || progressed || workers > 1) {
+					want.push_back(i);
+					rects.push_back(rmd_tile_rect{(uint32_t)t.left, (uint32_t)t.top, (uint32_t)t.width, (uint32_t)t.height});
+					pixels += t.width * t.height;
 				}
 			}
-			std::lock_guard<std::mutex> lock(sh->m);
-			sh->in_flight -= mine.size();
+			if (!want.empty()) {
+				std::shared_ptr<void> block = pool->get(ctx, pixels * 24);
+				check(rmd_framebuffer_download_tiles_async(ctx, fb, (uint32_t)W, (uint32_t)H, rects.data(), (uint32_t)rects.size(), static_cast<double *>(block.get())), ctx, "rmd_framebuffer_download_tiles");
+				Vector3 *p = static_cast<Vector3 *>(block.get());
+				for (size_t i : want) {
+					mine[i].data = TileData(block, p, mine[i].width * mine[i].height);
+					p += mine[i].width * mine[i].height;
+				}
+			}
 			for (Tile &t : mine) {
-				if (t.sample_count == st.sample_count) { // :211-212
-					sh->channel.push_back(Message{Message::TileFinished, std::move(t)});
-				} else { // :214-219
-					if (st.samples_per_iteration != 0 && t.sample_count % st.samples_per_iteration == 0)
-						sh->channel.push_back(Message{Message::TileProgressed, t});
-					sh->queue.push_back(std::move(t));
+				const bool finished = t.sample_count == st.sample_count;
+				const bool progressed = !finished && st.samples_per_iteration != 0 && t.sample_count % st.samples_per_iteration == 0;
+				if (finished) {
+					t.resident = -1;
+					next.messages.push_back(Message{Message::TileFinished, std::move(t)});
+					next.taken++;
+				} else if (workers > 1) { // back to the shared queue with its sums in RAM, once they have arrived
+					t.resident = -1;
+					if (progressed) next.messages.push_back(Message{Message::TileProgressed, t});
+					next.requeue.push_back(std::move(t));
+					next.taken++;
+				} else { // one GPU: the tile goes back to the queue at once, sums resident; its snapshot follows when it has arrived
+					if (progressed) {
+						Tile snapshot = t;
+						snapshot.resident = -1;
+						next.messages.push_back(Message{Message::TileProgressed, std::move(snapshot)});
+					}
+					t.data = TileData();
+					resident_requeue.push_back(std::move(t));
 				}
 			}
-			sh->cv.notify_all();
+			{
+				std::lock_guard<std::mutex> lock(sh->m);
+				sh->in_flight -= resident_requeue.size();
+				for (Tile &t : resident_requeue) sh->queue.push_back(std::move(t));
+				sh->cv.notify_all();
+			}
+			pending = std::move(next);
 		}
+		flush();
+		check(rmd_context_synchronize(ctx), ctx, "rmd_context_synchronize"); // a device fault of the last launch surfaces here at the latest
 	} catch (const std::exception &e) {
 		std::lock_guard<std::mutex> lock(sh->m);
 		if (sh->error.empty()) sh->error = e.what(); // the waiting workers see it and leave
@@ -245,13 +354,16 @@ TaskHandle render_tiled(const Scene &scene, const Settings &settings) {
 	for (const rmd_tile_rect &r : generate_tiles(cam.backbuffer_width, cam.backbuffer_height, settings.tile_size)) {
 		Tile t;
 		t.left = r.left, t.top = r.top, t.width = r.width, t.height = r.height;
-		t.data.assign((size_t)r.width * r.height, Vector3{0, 0, 0});
+		// (no data: a fresh tile's sums are the zeros of its worker's device framebuffer)
 		h.shared_->queue.push_back(std::move(t));
 	}
 	const size_t workers = std::max<size_t>(1, settings.worker_count);
 	const size_t batch = std::max<size_t>(1, (h.shared_->queue.size() + workers * 4 - 1) / (workers * 4));
 	h.shared_->alive = workers;
-	for (size_t w = 0; w < workers; w++) h.workers_.emplace_back(worker_main, h.shared_, (int)w, scene, settings, workers == 1 ? h.shared_->queue.size() : batch);
+	// worker w drives GPU w; RAYMOND_REHEARSE_ON_DEVICE0=1 (tests on a one-GPU box) gives every worker its own context on GPU 0
+	const bool rehearse = std::getenv("RAYMOND_REHEARSE_ON_DEVICE0") != nullptr;
+	for (size_t w = 0; w < workers; w++)
+		h.workers_.emplace_back(worker_main, h.shared_, rehearse ? 0 : (int)w, (int)w, workers, scene, settings, workers == 1 ? h.shared_->queue.size() : batch);
 	return h;
 }
 
@@ -279,6 +391,11 @@ std::vector<Vector3> TaskHandle::await() {
 			}
 	}
 	return out;
+}
+
+double TaskHandle::setup_seconds() const {
+	std::lock_guard<std::mutex> lock(shared_->m);
+	return shared_->setup_s;
 }
 
 bool TaskHandle::finished() const {

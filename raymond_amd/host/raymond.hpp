@@ -11,7 +11,9 @@
 //
 // What differs: a worker is a GPU (an rmd_context) instead of an OS thread, and a worker's unit of work is
 // "samples_per_iteration samples for a batch of tiles" in one rmd_render_tiles call instead of one sample of one
-// tile.  Failures throw raymond::Error (the reference panics).
+// tile.  A tile's running sums stay RESIDENT in its worker's device framebuffer between passes; what crosses the bus is what a
+// message carries — a pass's TileProgressed snapshots, the TileFinished tiles — downloaded in Tile.data layout on a copy stream
+// while the next pass renders.  Failures throw raymond::Error (the reference panics).
 #pragma once
 #include <array>
 #include <condition_variable>
@@ -123,9 +125,39 @@ struct Settings { // src/trace.rs:42-55 (+ the RNG seed the reference lacks)
 	bool end_black_paths = false;
 };
 
+// core/src/tile.rs:13 `data: Vec<Vector3>` — the running sums of a tile, width * height of them, row-major.  Here a VIEW: the tiles of one
+// message batch (a progressive pass's TileProgressed snapshots, or the TileFinished tiles) share the one page-locked block their pixels were
+// downloaded into (rmd_framebuffer_download_tiles: the block is in Tile.data layout already), kept alive by its last tile — where the
+// reference clones 24 KB per tile and message (src/trace.rs:212,218).  A tile that was not produced by a download owns its block.
+class TileData {
+  public:
+	TileData() = default;
+	explicit TileData(size_t n) : block_(new Vector3[n](), std::default_delete<Vector3[]>()), p_(static_cast<Vector3 *>(block_.get())), n_(n) {}
+	TileData(std::shared_ptr<void> block, Vector3 *first, size_t n) : block_(std::move(block)), p_(first), n_(n) {}
+	size_t size() const { return n_; }
+	bool empty() const { return n_ == 0; }
+	const Vector3 &operator[](size_t i) const { return p_[i]; }
+	Vector3 &operator[](size_t i) { return p_[i]; }
+	const Vector3 *data() const { return p_; }
+	Vector3 *data() { return p_; }
+	const Vector3 *begin() const { return p_; }
+	const Vector3 *end() const { return p_ + n_; }
+	void push_back(const Vector3 &v) { // (tests build small tiles by hand)
+		TileData grown(n_ + 1);
+		for (size_t i = 0; i < n_; i++) grown[i] = p_[i];
+		grown[n_] = v;
+		*this = std::move(grown);
+	}
+
+  private:
+	std::shared_ptr<void> block_;
+	Vector3 *p_ = nullptr;
+	size_t n_ = 0;
+};
 struct Tile { // core/src/tile.rs:7-14
 	size_t sample_count = 0, width = 0, height = 0, left = 0, top = 0;
-	std::vector<Vector3> data; // running sums, width*height
+	TileData data; // running sums, width*height.  EMPTY while the tile waits in the queue with its sums resident on a GPU (`resident`)
+	int resident = -1; // the worker (GPU) whose device framebuffer holds the tile's sums; -1: `data` does (an extension: the reference's tiles live in RAM)
 };
 struct Message { // src/trace.rs:62-66
 	enum Kind { TileFinished, TileProgressed } kind;
@@ -143,6 +175,7 @@ class TaskHandle {
 	std::optional<Message> poll();        // :115-117
 	void async_await();                   // :119-134: drains leading TileProgressed messages into the callback
 	bool finished() const;                // extension: alive_thread_count == 0 (what await() polls for, :89)
+	double setup_seconds() const;         // extension (measurement): the longest a worker took to get ready — context, scene upload, framebuffer
 	~TaskHandle();
 	TaskHandle(TaskHandle &&) = default;
 	struct Shared; // queue + channel shared with the workers (implementation detail)

@@ -34,6 +34,12 @@ SIGNATURES = {
     "rmd_framebuffer_zero": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "rmd_framebuffer_download": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "rmd_framebuffer_upload": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "rmd_framebuffer_download_tiles": (C.c_int32, [_vp, _vp, C.c_uint32, C.c_uint32, _P(abi.TileRect), C.c_uint32, _vp]),
+    "rmd_framebuffer_download_tiles_async": (C.c_int32, [_vp, _vp, C.c_uint32, C.c_uint32, _P(abi.TileRect), C.c_uint32, _vp]),
+    "rmd_context_wait_transfers": (C.c_int32, [_vp]),
+    "rmd_framebuffer_upload_tiles": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _P(abi.TileRect), C.c_uint32]),
+    "rmd_host_alloc": (C.c_int32, [_vp, C.c_size_t, _P(_vp)]),
+    "rmd_host_free": (C.c_int32, [_vp, _vp]),
     "rmd_render_tiles": (
         C.c_int32,
         [_vp, _vp, _P(abi.Camera), _P(abi.Settings), _P(abi.TileRect), C.c_uint32, _vp],

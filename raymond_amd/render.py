@@ -115,6 +115,24 @@ class Framebuffer:
         assert arr.size == self.n
         self.ctx.check(self.ctx.L.rmd_framebuffer_upload(self.ctx.handle, arr.ctypes.data_as(C.c_void_p), self.ptr, self.n))
 
+    def download_tiles(self, tiles):
+        """rmd_framebuffer_download_tiles: the pixels of `tiles` (left, top, width, height) as ONE packed array, tile after tile, each
+        row-major (height, width, 3) — core::tile::Tile.data's layout; returns the list of per-tile views."""
+        arr = tile_array(tiles)
+        n = sum(w * h for (_, _, w, h) in tiles)
+        out = np.empty(n * 3, dtype=np.float64)
+        self.ctx.check(self.ctx.L.rmd_framebuffer_download_tiles(self.ctx.handle, self.ptr, self.width, self.height, arr, len(tiles), out.ctypes.data_as(C.c_void_p)))
+        views, at = [], 0
+        for (_, _, w, h) in tiles:
+            views.append(out[at : at + w * h * 3].reshape(h, w, 3))
+            at += w * h * 3
+        return views
+
+    def upload_tiles(self, tiles, datas):
+        """rmd_framebuffer_upload_tiles: the inverse (datas: one (height, width, 3) array per tile)."""
+        packed = np.ascontiguousarray(np.concatenate([np.asarray(d, dtype=np.float64).reshape(-1) for d in datas]))
+        self.ctx.check(self.ctx.L.rmd_framebuffer_upload_tiles(self.ctx.handle, packed.ctypes.data_as(C.c_void_p), self.ptr, self.width, self.height, tile_array(tiles), len(tiles)))
+
     def close(self):
         if self.owned and self.ptr:
             self.ctx.L.rmd_framebuffer_free(self.ctx.handle, self.ptr)

@@ -658,11 +658,11 @@ def test_a_mesh_scene_with_many_objects_keeps_the_persistent_form_with_fewer_wav
     """Round 4's advisor: a grid scene's persistent workgroup needs 6.7 KB of LDS per wave beside the masks and 128 bytes per object; with ~100
     objects 16 waves no longer fit and the launch silently fell back to one wave per item while rmd_last_launch_info still said
     `persistent`.  Now the workgroup shrinks (the kernel takes its wave count from blockDim) and the info reports the form that was launched:
-    a mesh + 100 spheres runs persistent with fewer than 16 waves, 900 spheres as one wave per item — same frame bit for bit in every form, and
-    the oracle's."""
+    a mesh + 450 spheres (58 KB of object table) runs persistent with fewer than 16 waves, 1100 spheres as one wave per item — same frame bit for
+    bit in every form, and the oracle's."""
     from raymond_amd.scene import Material, Object, Sphere
 
-    for n_spheres, want_persistent in ((100, 1), (900, 0)):
+    for n_spheres, want_persistent in ((450, 1), (1100, 0)):
         rng = np.random.default_rng(n_spheres)
         sc = scenes.mesh_scene(scenes.lumpy_sphere_mesh(13))
         for i in range(n_spheres):
@@ -810,6 +810,57 @@ def test_spheres_sum_inside_the_kernel_matches_the_direct_mode(gpu_ctx, oracle):
         assert img.tobytes() == out[(1, 0, 1)].tobytes(), key
     assert rel_close(out[(1, 0, 1)], want, 1e-9).mean() > 0.999
     fb.close(), ds.close()
+
+
+def test_tile_rectangles_move_between_the_framebuffer_and_packed_host_buffers(gpu_ctx):
+    """rmd_framebuffer_download_tiles / _upload_tiles (what a host scheduler uses to keep tile sums resident on the GPU and move only the tiles a
+    message carries): every tile comes back as the same bits a whole-frame download holds there, in Tile.data layout, for ragged tiles, a subset in
+    any order, and two downloads in flight; an upload changes exactly the tiles it names; rectangles outside the frame are refused."""
+    import ctypes as C
+
+    from raymond_amd.scene import tile_array
+
+    W, H = 203, 117
+    rng = np.random.default_rng(9)
+    frame = rng.uniform(-1, 1, (H, W, 3))
+    frame[5, 7] = [np.nan, np.inf, -0.0]
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    fb.upload(frame)
+    tiles = generate_tiles(W, H, (32, 32))
+    order = list(rng.permutation(len(tiles)))
+    some = [tiles[i] for i in order[: len(tiles) // 2]] + [(0, 0, 1, 1), (W - 3, H - 2, 3, 2), (0, 0, W, H)]
+    for sel in (tiles, some):
+        for (l, t, w, h), got in zip(sel, fb.download_tiles(sel)):
+            assert same_bits(got, frame[t : t + h, l : l + w]).all(), (l, t, w, h)
+    # two asynchronous downloads in flight, then a third (it waits for the first), into pinned memory
+    L = gpu_ctx.L
+    bufs = []
+    for k in range(3):
+        sel = tiles[k::3]
+        n = sum(w * h for (_, _, w, h) in sel) * 3
+        p = C.c_void_p()
+        gpu_ctx.check(L.rmd_host_alloc(gpu_ctx.handle, n * 8, C.byref(p)))
+        gpu_ctx.check(L.rmd_framebuffer_download_tiles_async(gpu_ctx.handle, fb.ptr, W, H, tile_array(sel), len(sel), p))
+        bufs.append((sel, n, p))
+    gpu_ctx.check(L.rmd_context_wait_transfers(gpu_ctx.handle))
+    for sel, n, p in bufs:
+        packed = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(n,)).copy()
+        at = 0
+        for (l, t, w, h) in sel:
+            assert same_bits(packed[at : at + w * h * 3].reshape(h, w, 3), frame[t : t + h, l : l + w]).all()
+            at += w * h * 3
+        gpu_ctx.check(L.rmd_host_free(gpu_ctx.handle, p))
+    # upload: only the named tiles change
+    new = [rng.uniform(2, 3, (h, w, 3)) for (_, _, w, h) in tiles[::4]]
+    fb.upload_tiles(tiles[::4], new)
+    want = frame.copy()
+    for (l, t, w, h), d in zip(tiles[::4], new):
+        want[t : t + h, l : l + w] = d
+    assert same_bits(fb.download(), want).all()
+    bad = tile_array([(W - 8, 0, 16, 16)])
+    out = np.zeros(16 * 16 * 3)
+    assert L.rmd_framebuffer_download_tiles(gpu_ctx.handle, fb.ptr, W, H, bad, 1, out.ctypes.data_as(C.c_void_p)) == abi.RMD_ERR_INVALID_ARGUMENT
+    fb.close()
 
 
 def test_host_buffer_entry_point_matches_device_path(gpu_ctx):

@@ -77,8 +77,12 @@ def test_render_without_a_gpu_fails_loudly(cli, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene,spi", [("spheres", 0), ("dragon:12", 0), ("spheres", 3), ("project", 0)])
-def test_cpp_render_tiled_equals_python_path(cli, gpu_ctx, tmp_path, scene, spi):
+@pytest.mark.parametrize("scene,spi,gpus", [("spheres", 0, 1), ("dragon:12", 0, 1), ("spheres", 3, 1), ("project", 0, 1), ("dragon:12", 2, 1), ("dragon:12", 2, 2), ("spheres", 0, 3)])
+def test_cpp_render_tiled_equals_python_path(cli, gpu_ctx, tmp_path, scene, spi, gpus):
+    """The C++ host mirror (tile queue, progressive passes, tile sums resident on the GPU between passes, only the tiles of a message downloaded —
+    on a copy stream while the next pass renders) gives the frame of one rmd_render_tiles call bit for bit: one pass, progressive passes
+    (7 spp in passes of 3 or 2: the last pass is shorter), and several workers (rehearsed on this box's one GPU: every worker its own context),
+    where a tile's sums travel through RAM from one GPU's framebuffer to another's."""
     W, H, spp, bounces = 96, 64, 7, 4
     ppm, raw = tmp_path / "o.ppm", tmp_path / "o.f64"
     if scene == "project":  # the spheres scene through its serde-JSON project file (core/src/project.rs)
@@ -86,7 +90,11 @@ def test_cpp_render_tiled_equals_python_path(cli, gpu_ctx, tmp_path, scene, spi)
 
         (tmp_path / "spheres.json").write_text(Project.from_scene(scenes.reflective_spheres()).dumps())
         scene = "project:%s" % (tmp_path / "spheres.json")
-    r = run(cli, "render", scene, W, H, spp, bounces, ppm, "--raw", raw, "--spi", spi)
+    os.environ["RAYMOND_REHEARSE_ON_DEVICE0"] = "1"
+    try:
+        r = run(cli, "render", scene, W, H, spp, bounces, ppm, "--raw", raw, "--spi", spi, "--gpus", gpus)
+    finally:
+        os.environ.pop("RAYMOND_REHEARSE_ON_DEVICE0", None)
     assert r.returncode == 0, r.stderr
     img_cpp = np.fromfile(raw).reshape(H, W, 3)
     sc = scenes.gold_dragon_standin(n=12) if scene.startswith("dragon") else scenes.reflective_spheres()
