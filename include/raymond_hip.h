@@ -221,7 +221,7 @@ enum {
 	RMD_TUNE_WALK_CUT = 5,     /* RMD_WALK_CUT: K + 1, where a grid-walk call of a wave stops stepping under its last K rays and leaves their
 	                              walks to the wave's next call (0 = the library's choice, K = 4; 1 = every call finishes every walk)      */
 	RMD_TUNE_SPLIT_MIN_SAMPLES = 6, /* RMD_SPLIT_MIN_SAMPLES: fewest samples per pixel a work item of a split launch may hold (0 = the library's
-	                              choice: 2 in scenes with grids, 64 without).  Launches with fewer than twice that run in direct mode      */
+	                              choice: 4 in scenes with grids — two items per wave tile from 4 samples per pixel on — 64 without)      */
 	RMD_TUNE_COUNT = 7
 };
 /* Free and total memory of the context's device, bytes (hipMemGetInfo): what a host that shares the GPU sizes its launches by. */

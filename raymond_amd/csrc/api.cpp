@@ -630,6 +630,9 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 		uint32_t min_samples = has_grid ? rmd::kSplitMinSamplesGrid : 64u;
 		if (ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] > 0) min_samples = (uint32_t)std::min<int64_t>(ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES], 1 << 20);
 		if (k > sample_count / min_samples) k = sample_count / min_samples;
+		// ... but two items per wave tile while each still holds two samples (C3 at 4 spp: 4.5 ms as two items of 2 samples, 5.1 as one item of 4:
+		// with one item per wave tile the mesh tiles' items are the launch's tail)
+		if (has_grid && k < 2u && sample_count >= 4u && ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] <= 0) k = 2u;
 	}
 	if (k > 64u) k = 64u;
 	while (k > 1u && (uint64_t)n_wave_tiles * k > 0x7FFFFFFFull) k--; // work items are indexed in 32 bits
