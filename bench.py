@@ -60,7 +60,7 @@ def load_counters():
         return json.load(f)
 
 
-def algorithmic_bytes_per_sample(name, spp, counters, all_cells=False):
+def algorithmic_bytes_per_sample(name, spp, counters, all_cells=False, work_done=False):
     """8*C + 76*T + 72*H + 24/spp bytes per sample (T triangle tests, H shaded mesh hits) with C = the visited cells that hold a
     triangle: only those gather their 8-byte entry from memory — an empty cell is answered by one bit of the occupancy mask in LDS, which
     is part of the data layout (round 2's advisor: "count 8 B only for occupied cells").  all_cells=True prices every
@@ -70,7 +70,14 @@ def algorithmic_bytes_per_sample(name, spp, counters, all_cells=False):
         return None
     n = float(c["samples"])
     cells = c["cells"] if all_cells or "occupied_cells" not in c else c["occupied_cells"]
-    return 8.0 * cells / n + 76.0 * c["tri_tests"] / n + 72.0 * c["mesh_hits"] / n + 24.0 / spp
+    tests = c["tri_tests"]
+    if work_done:
+        # the tests the kernel RUNS: the reference's minus the re-tests of triangles the previous cell of the same walk listed too (they missed there,
+        # they miss here: the kernel's per-entry-direction lists leave them out, device_types.hpp) — oracle counter `retests`
+        if "retests" not in c:
+            return None
+        tests = c["tri_tests"] - c["retests"]
+    return 8.0 * cells / n + 76.0 * tests / n + 72.0 * c["mesh_hits"] / n + 24.0 / spp
 
 
 def usable_cpus():
@@ -168,6 +175,29 @@ def bound_by_counters(rl):
         "" if not busy else "; the instruction stream at its classes' measured issue costs keeps the vector ALUs busy %.2f - %.2f of the time" % (busy["low"], busy["high"]),
         "n/a" if mem is None else "%.3f" % mem, " (PMC figures are STALE: collected at other sources)" if v.get("stale") else "")
     return bound, text
+
+
+def host_api_block(ctx):
+    """raymond_amd/host/raymond_cli hostapi ... (cli.cpp): one JSON line per run; a child process (its own HIP runtime)."""
+    import subprocess
+
+    cli = os.path.join(ROOT, "raymond_amd", "host", "raymond_cli")
+    if not os.path.exists(cli):
+        return {"error": "raymond_amd/host/raymond_cli is not built"}
+    block = {"how": "raymond_cli hostapi: scene built first, a tiny untimed render initialises the HIP runtime, then render_tiled(scene, settings) is timed from the "
+                    "call to the last TileFinished message (best of 3); wall_ms includes the worker's context creation, the scene upload (setup_ms) and every "
+                    "transfer; tile sums stay resident on the GPU between passes, the tiles of a pass's messages are downloaded on a copy stream while the next pass renders"}
+    for key, scene in (("C2", "spheres"), ("C3", "dragon")):
+        for spi in (0, 8):
+            r = subprocess.run([cli, "hostapi", scene, "1920", "1080", "500", "5", str(spi)], capture_output=True, text=True, timeout=300)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            name = "%s_%s" % (key, "one_pass" if spi == 0 else "progressive_%d_spp_a_pass" % spi)
+            block[name] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or r.stdout)[-300:]}
+    for key in ("C2", "C3"):
+        a, b = block.get(key + "_one_pass", {}), block.get(key + "_progressive_8_spp_a_pass", {})
+        if "msamples_per_s" in a and "msamples_per_s" in b:
+            block[key + "_progressive_over_one_pass"] = round(b["msamples_per_s"] / a["msamples_per_s"], 4)
+    return block
 
 
 def launch_ranks(n):
@@ -285,7 +315,7 @@ def main():
             fb_t.zero_()
             render.render_tiles(ctx, ds, cam, st, arr, fb, 0, st.sample_count, sync=False)
             if reduce and abi_comm is not None:
-                ctx.check(ctx.L.rmd_reduce_framebuffer(abi_comm, fb_t.data_ptr(), fb_t.numel(), 0))  # ncclReduce on the context's stream
+                ctx.check(ctx.L.rmd_reduce_framebuffer_async(abi_comm, fb_t.data_ptr(), fb_t.numel(), 0))  # ncclReduce enqueued on the context's stream: steps queue back to back
             elif gather is not None:
                 gather(dist, fb_t, stage_host=(backend != "nccl"))
             elif reduce and dist is not None:
@@ -320,12 +350,19 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        checksum = float(fb_t.sum().item()) if rank == 0 else 0.0
+        # the frame's checksum: the sum of its finite values (a reference-identical mesh frame holds the pixels the reference itself makes NaN) and,
+        # beside it, how many pixels hold a non-finite channel
+        checksum, nonfinite = 0.0, 0
+        if rank == 0:
+            finite = torch.isfinite(fb_t)
+            checksum = float(torch.where(finite, fb_t, torch.zeros_like(fb_t)).sum().item())
+            nonfinite = int((~finite.view(-1, 3)).any(dim=1).sum().item())
+        info = ctx.last_launch_info()
         ds.close()
         samples_per_step = W * H * st.sample_count
         my_samples = shard.shard_samples(share) * st.sample_count
         return dict(st=st, W=W, H=H, elapsed=elapsed, kernel_ms=kernel_ms, samples_per_step=samples_per_step,
-                    my_samples=my_samples, checksum=checksum, n_tiles=len(tiles))
+                    my_samples=my_samples, checksum=checksum, nonfinite_pixels=nonfinite, n_tiles=len(tiles), passes=int(info.passes), split_k=int(info.split_k))
 
     name = args.workload
     spp = args.spp if args.spp is not None else scenes.CONFIGS[name][3]
@@ -364,7 +401,7 @@ def main():
         full = run_workload(name, spp, 1, 1, reduce=False, mode="trace")
         out["tracing_black_paths"] = {
             "value": round(full["samples_per_step"] / full["elapsed"] / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(full["elapsed"] * 1e3, 3),
-            "checksum": full["checksum"],
+            "checksum": full["checksum"], "nonfinite_pixels": full["nonfinite_pixels"],
             "note": "rmd_settings.flags = RMD_RENDER_TRACE_BLACK_PATHS: paths whose throughput is exactly (0, 0, 0) are traced on (1.8x the path segments); the same frame "
                     "bit for bit (same checksum) — the segment count the CPU baseline executes; not what `value` measures",
         }
@@ -379,7 +416,8 @@ def main():
         # mesh scenes: persistent render kernel + sum_kernel; spheres: the render kernel's waves add the samples themselves
         kname = ("rmd::render_kernel<1, true, true> + rmd::sum_kernel" if scenes.CONFIGS[name][0] != "reflective_spheres"
                  else "rmd::render_kernel<1, false, true> (persistent workgroups, ordered sample sum inside)")
-        out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"]}
+        out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"],
+                         "nonfinite_pixels": main_run["nonfinite_pixels"]}
         traffic = load_traffic(name, spp) if world == 1 else None
         rl = {
             "bound": "hbm", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -417,8 +455,13 @@ def main():
                 "msamples_per_s": round(rr["samples_per_step"] / (avg_ms * 1e-3) / 1e6, 2),
                 "bytes_per_sample": round(bps, 2), "bytes_per_launch": bps * rr["samples_per_step"],
                 "frac_with_every_visited_cell_at_8_bytes": algorithmic_bytes_per_sample(counter_key, rspp, counters, all_cells=True) * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "checksum": rr["checksum"],
+                "checksum": rr["checksum"], "nonfinite_pixels": rr["nonfinite_pixels"],
             }
+            done = algorithmic_bytes_per_sample(counter_key, rspp, counters, work_done=True)
+            if done is not None:
+                # the contractual `frac` prices the REFERENCE's triangle tests; this one prices the tests the kernel runs (22 % fewer)
+                leg["bytes_per_sample_of_work_done"] = round(done, 2)
+                leg["frac_of_work_done"] = done * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             if traffic is not None:
                 # L2<->fabric bytes per launch by PMC (upper bound on HBM bytes: Infinity-Cache hits are included)
                 leg["measured_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 3)
@@ -462,6 +505,13 @@ def main():
                         scenes.CONFIGS[cname][0], r["W"], r["H"], r["st"].bounce_limit, ", thin lens (RMD_RENDER_DOF)" if r["st"].use_dof else "", cspp, scenes.CONFIGS[cname][3])})
                     cfg[cname]["reference_identical" if mode == "default" else "ending_black_paths"] = {
                         "kernel_ms": round(ms, 3), "msamples_per_s": round(r["samples_per_step"] / (ms * 1e-3) / 1e6, 2)}
+            # ... and ONE launch each of the two configurations BASELINE.json names for 8 GPUs at their FULL sample counts, flags 0 (reference-identical):
+            # the per-sample scratch does not hold all samples at once, so the library runs them as several passes (rmd_last_launch_info)
+            for cname in ("C4", "C5"):
+                r = run_workload(cname, scenes.CONFIGS[cname][3], 1, 0, reduce=False, mode="default")
+                ms = sum(r["kernel_ms"]) / len(r["kernel_ms"])
+                cfg[cname]["full_configuration"] = {"spp": scenes.CONFIGS[cname][3], "kernel_ms": round(ms, 1), "passes": r["passes"], "msamples_per_s": round(r["samples_per_step"] / (ms * 1e-3) / 1e6, 2),
+                                                   "nonfinite_pixels": r["nonfinite_pixels"], "checksum": r["checksum"]}
             cfg["C3"] = {"workload": rl["workload"], "reference_identical": {"kernel_ms": rl["avg_ms"], "msamples_per_s": rl["msamples_per_s"]},
                          "ending_black_paths": {"kernel_ms": end["avg_ms"], "msamples_per_s": end["msamples_per_s"]}}
             cfg["C2"] = {"workload": out["config"]["workload"], "reference_identical": {"kernel_ms": out["kernel"]["avg_ms"], "msamples_per_s": round(value, 2)},
@@ -470,6 +520,11 @@ def main():
     elif rank == 0:
         out["roofline"] = out.get("roofline_%s" % name.lower())
 
+    # What a drop-in caller gets: C2 and C3 end to end through the reference-shaped API — raymond_amd/host's render_tiled (the C++ stand-in for
+    # integration/gpu.rs: tile queue, progressive passes, TileProgressed / TileFinished messages), wall time from the call to the last
+    # TileFinished, once in one pass (samples_per_iteration 0) and once progressively (8 samples a pass: src/trace.rs:207-219).
+    if rank == 0 and world == 1 and not args.no_roofline_leg and not args.lean:
+        out["host_api"] = host_api_block(ctx)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -531,7 +586,7 @@ def main():
         ctx.L.rmd_comm_destroy(abi_comm)
     ctx.close()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, allow_nan=False), flush=True)
     if dist is not None:
         barrier()
         dist.destroy_process_group()

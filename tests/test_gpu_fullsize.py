@@ -251,6 +251,21 @@ def test_rccl_entry_points_world_of_one(gpu_ctx):
     gpu_ctx.check(L.rmd_reduce_framebuffer(comm, fb.ptr, fb.n, 0))
     assert fb.download().tobytes() == data.tobytes()
     assert L.rmd_reduce_framebuffer(comm, fb.ptr, fb.n, 3) == abi.RMD_ERR_INVALID_ARGUMENT
+    # the enqueue-only form (what lets a rank queue zeroing, render and reduce of several frames back to back): three frames queued, one wait
+    st = Settings(scenes.camera(64, 32), sample_count=3, bounce_limit=3, seed=scenes.SEED)
+    ds = render.DeviceScene(gpu_ctx, scenes.reflective_spheres())
+    tiles = generate_tiles(64, 32, (32, 32))
+    fb.zero()
+    render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
+    want = fb.download()
+    for _ in range(3):
+        fb.zero()
+        render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb, sync=False)
+        gpu_ctx.check(L.rmd_reduce_framebuffer_async(comm, fb.ptr, fb.n, 0))
+    gpu_ctx.synchronize()
+    assert fb.download().tobytes() == want.tobytes()
+    assert L.rmd_reduce_framebuffer_async(comm, fb.ptr, fb.n, -1) == abi.RMD_ERR_INVALID_ARGUMENT
+    ds.close()
     L.rmd_comm_destroy(comm)
     fb.close()
 
