@@ -10,7 +10,7 @@
 //!     (cli_old/src/main.rs:152) — it returns the same `TaskHandle`, so `await`/`poll`/`async_await` are unchanged.
 #![allow(non_camel_case_types)]
 
-use std::os::raw::c_char;
+use std::os::raw::{c_char, c_void};
 use std::ptr;
 use std::sync::atomic::{AtomicUsize, Ordering};
 use std::sync::{mpsc, Arc};
@@ -37,6 +37,7 @@ pub struct rmd_grid_desc {
     pub bbox_min: [f64; 3], pub bbox_max: [f64; 3], pub resolution: [u32; 3], _pad: u32, pub cell_size: [f64; 3],
     pub cells: *const u32, pub n_cells: u64, pub mapping_table: *const u32, pub n_mapping: u64,
     pub tri_pos: *const f64, pub tri_nrm: *const f64, pub n_tris: u64,
+    pub built: *const c_void, // NULL, or the rmd_grid_build the pointers belong to (rmd_grid_build_describe sets it: device tables derived once per build)
 }
 #[repr(C)]
 pub struct rmd_camera { pub backbuffer_width: u32, pub backbuffer_height: u32, pub fov_vert: f64, pub position: [f64; 3], pub focal_length: f64, pub aperture_radius: f64 }
@@ -57,8 +58,9 @@ extern "C" {
     fn rmd_scene_destroy(scene: *mut rmd_scene);
     fn rmd_framebuffer_alloc(ctx: *mut rmd_context, width: u32, height: u32, out: *mut *mut f64) -> i32;
     fn rmd_framebuffer_free(ctx: *mut rmd_context, dev: *mut f64) -> i32;
-    fn rmd_framebuffer_upload(ctx: *mut rmd_context, host: *const f64, dev: *mut f64, n: usize) -> i32;
-    fn rmd_framebuffer_download(ctx: *mut rmd_context, dev: *const f64, host: *mut f64, n: usize) -> i32;
+    // tile rectangles <-> a packed buffer in Tile.data layout (tile sums stay resident on the GPU; only what a message carries is moved)
+    fn rmd_framebuffer_upload_tiles(ctx: *mut rmd_context, host_packed: *const f64, dev: *mut f64, width: u32, height: u32, rects: *const rmd_tile_rect, n_rects: u32) -> i32;
+    fn rmd_framebuffer_download_tiles(ctx: *mut rmd_context, dev: *const f64, width: u32, height: u32, rects: *const rmd_tile_rect, n_rects: u32, host_packed: *mut f64) -> i32;
     fn rmd_render_tiles(ctx: *mut rmd_context, scene: *const rmd_scene, camera: *const rmd_camera, settings: *const rmd_settings,
                         tiles: *const rmd_tile_rect, n_tiles: u32, accum_dev: *mut f64) -> i32;
 }
@@ -118,6 +120,7 @@ fn flatten(scene: &Scene) -> (Vec<rmd_object>, FlatGrids) {
             resolution: [g.resolution.x as u32, g.resolution.y as u32, g.resolution.z as u32], _pad: 0, cell_size: v3(g.cell_size),
             cells: f.cells[i].as_ptr(), n_cells: f.cells[i].len() as u64, mapping_table: f.maps[i].as_ptr(), n_mapping: f.maps[i].len() as u64,
             tri_pos: f.pos[i].as_ptr(), tri_nrm: f.nrm[i].as_ptr(), n_tris: g.mesh.triangles.len() as u64,
+            built: ptr::null(), // these tables are the reference's own AccGrid, converted: nothing to reuse
         });
     }
     (objects, f)
@@ -140,7 +143,9 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
     let cs = &settings.camera_settings;
     let n_tiles = ((cs.backbuffer_width + tw - 1) / tw) * ((cs.backbuffer_height + th - 1) / th);
     // a quarter of a GPU's share per pop, so that every GPU gets work and the tail stays short (1080p: 2040 tiles, 8 GPUs -> 64)
-    let batch_size = ((n_tiles + settings.worker_count * 4 - 1) / (settings.worker_count * 4)).max(1);
+    let gpu_workers = settings.worker_count;
+    // one GPU: every tile in one launch per pass; several: a quarter of a GPU's share per pop
+    let batch_size = if gpu_workers == 1 { n_tiles } else { ((n_tiles + gpu_workers * 4 - 1) / (gpu_workers * 4)).max(1) };
     for gpu in 0..settings.worker_count {
         let (queue, sender, thread_count, in_flight) = (queue.clone(), sender.clone(), thread_count.clone(), in_flight.clone());
         let (scene, settings) = (scene.clone(), settings.clone()); // :182-185
@@ -156,7 +161,10 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
                                       position: v3(cam.transform.position), focal_length: cam.focal_length, aperture_radius: cam.aperture_radius };
             let mut fb = ptr::null_mut();
             check(ctx, rmd_framebuffer_alloc(ctx, w as u32, h as u32, &mut fb));
-            let mut host = vec![0.0f64; w * h * 3];
+            // The tiles' running sums stay RESIDENT in `fb` (zeroed by rmd_framebuffer_alloc: a fresh tile's sums) between passes; what crosses the bus
+            // is what a message carries.  `resident[i]`: the sums of tile i are in THIS worker's framebuffer (with several GPU workers a tile that
+            // goes back to the shared queue takes its sums along in tile.data, and the worker that pops it next uploads them).
+            let mut packed: Vec<f64> = Vec::new();
             // samples per pass: all of them at once, or `samples_per_iteration` when progress messages are wanted (:217)
             let pass = if settings.samples_per_iteration != 0 { settings.samples_per_iteration } else { settings.sample_count };
             loop {
@@ -177,38 +185,45 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
                 let begin = batch[0].sample_count;
                 let n = pass.min(settings.sample_count - begin);
                 let rects: Vec<rmd_tile_rect> = batch.iter().map(|t| rmd_tile_rect { left: t.left as u32, top: t.top as u32, width: t.width as u32, height: t.height as u32 }).collect();
+                // several GPU workers: tiles whose earlier passes another GPU rendered arrive with their sums in tile.data (Tile.data layout IS the
+                // packed layout of rmd_framebuffer_upload_tiles: row-major within the tile, one tile after the other)
+                if gpu_workers > 1 && begin != 0 {
+                    packed.clear();
+                    for tile in &batch { for v in &tile.data { packed.extend_from_slice(&[v.x, v.y, v.z]); } }
+                    check(ctx, rmd_framebuffer_upload_tiles(ctx, packed.as_ptr(), fb, w as u32, h as u32, rects.as_ptr(), rects.len() as u32));
+                }
                 // flags: 0 — the drop-in mode.  The reference's loop calls the pinhole generate_primary_ray whatever cam.aperture_radius holds (:199);
                 // RMD_RENDER_DOF (1) would opt into generate_primary_ray_with_dof, which the reference defines but never calls.  With 0 every sample
-                // is the reference's, NaN for NaN: paths whose throughput is exactly zero are ended only in scenes without a mesh, where that is
-                // provably exact; RMD_RENDER_END_BLACK_PATHS (4) would end them on mesh scenes too (1.6x faster; a sample the reference makes
-                // 0 x NaN = NaN then comes out 0 — raymond_hip.h)
+                // is the reference's, NaN for NaN: paths whose throughput is exactly zero are ended only in scenes without a mesh whose parameters
+                // are all finite and regular, where that is provably exact; RMD_RENDER_END_BLACK_PATHS (4) would end them on mesh scenes too
+                // (1.6x faster; a sample the reference makes 0 x NaN = NaN then comes out 0 — raymond_hip.h)
                 let st = rmd_settings { bounce_limit: settings.bounce_limit as u32, sample_begin: begin as u32, sample_count: n as u32, flags: 0, seed };
-                // the tiles' running sums go up, the kernel adds samples begin..begin+n to them one by one (`+=` of :203, in sample
-                // order: progressive passes give the same bits as one pass), and the sums come back
-                for tile in &batch {
-                    for y in 0..tile.height {
-                        for x in 0..tile.width {
-                            let (p, v) = (((tile.left + x) + (tile.top + y) * w) * 3, tile.data[x + y * tile.width]);
-                            host[p] = v.x; host[p + 1] = v.y; host[p + 2] = v.z;
-                        }
-                    }
-                }
-                check(ctx, rmd_framebuffer_upload(ctx, host.as_ptr(), fb, w * h * 3));
+                // the kernel adds samples begin..begin+n to the resident sums one by one (`+=` of :203, in sample order: progressive passes give
+                // the same bits as one pass).  RMD_ERR_DEVICE_FAULT (8) here means the launch was cut short: check() panics, as the reference would
                 check(ctx, rmd_render_tiles(ctx, dev_scene, &camera, &st, rects.as_ptr(), rects.len() as u32, fb)); // replaces :197-205
-                check(ctx, rmd_framebuffer_download(ctx, fb, host.as_mut_ptr(), w * h * 3));
+                // what has to come to the host: finished tiles (:211-212), progress snapshots (:217-219), tiles that may change GPU
+                let finished = begin + n == settings.sample_count;
+                let snapshot = !finished && settings.samples_per_iteration != 0;
+                if finished || snapshot || gpu_workers > 1 {
+                    packed.resize(rects.iter().map(|r| (r.width * r.height * 3) as usize).sum(), 0.0);
+                    // (the C++ mirror, raymond_amd/host/raymond.cpp, uses rmd_framebuffer_download_tiles_async into page-locked memory
+                    // (rmd_host_alloc) and sends the messages of batch k while batch k + 1 renders: rmd_context_wait_transfers)
+                    check(ctx, rmd_framebuffer_download_tiles(ctx, fb, w as u32, h as u32, rects.as_ptr(), rects.len() as u32, packed.as_mut_ptr()));
+                }
                 let held = batch.len();
+                let mut at = 0usize;
                 for mut tile in batch {
-                    for y in 0..tile.height {
-                        for x in 0..tile.width {
-                            let p = ((tile.left + x) + (tile.top + y) * w) * 3;
-                            tile.data[x + y * tile.width] = Vector3::new(host[p], host[p + 1], host[p + 2]);
-                        }
+                    let len = tile.width * tile.height;
+                    if finished || snapshot || gpu_workers > 1 {
+                        tile.data.clear();
+                        tile.data.extend(packed[at * 3..(at + len) * 3].chunks_exact(3).map(|c| Vector3::new(c[0], c[1], c[2])));
                     }
+                    at += len;
                     tile.sample_count += n; // :207
                     if tile.sample_count == settings.sample_count {
                         sender.send(Message::TileFinished(tile)).unwrap(); // :211-212
                     } else {
-                        queue.push(tile.clone()); // :214
+                        queue.push(tile.clone()); // :214 (one GPU: the clone's data is not read again — the sums are in `fb`)
                         if settings.samples_per_iteration != 0 { sender.send(Message::TileProgressed(tile)).unwrap(); } // :217-219
                     }
                 }

@@ -460,6 +460,12 @@ RMD_DEV V3 sel(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ?
 // Fresnel term; only the polar angle's sin/cos, the reflection vector and the D/G terms stay divergent.  Every lane still
 // performs exactly its own branch's operations in the reference's order.
 // Must be called in wave-uniform control flow; a lane with neither flag set is left untouched.
+// A register (pair) the compiler may fill with anything: the value of a variable in the lanes that never use it.
+#ifndef RMD_NO_UNDEF
+#define RMD_UNDEF(v) asm volatile("" : "=v"(v));
+#else
+#define RMD_UNDEF(v) v = 0.0; // (A/B: the stand-in values of rounds 1 - 4)
+#endif
 struct NextRayShadeIn {
 	V3 normal, frag, color;
 	double roughness, metal;
@@ -467,7 +473,10 @@ struct NextRayShadeIn {
 RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const NextRayShadeIn &in, V3 cam_pos, uint32_t prim_x, uint32_t prim_y, Rng &rng,
                       V3 &ro, V3 &rd, V3 &T) {
 	const bool gen = do_shade || do_prim;
-	double u_first = 0.0, u_second = 0.0;
+	// (values that only the lanes of one kind use carry no stand-in for the others: a stand-in is a move per register where it is made and a
+	// select where the branches meet — RMD_UNDEF)
+	double u_first, u_second;
+	RMD_UNDEF(u_first) RMD_UNDEF(u_second)
 	const double r = (double)rng.lobe_bits * (1.0 / 4194304.0); // shade only (:260): the 22-bit uniform of the path's previous block
 	if (gen) {
 		uint32_t w0, w1, w2, w3;
@@ -477,9 +486,11 @@ RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const 
 		rng.lobe_bits = Rng::spare22(w0, w2); // for the next shaded depth
 	}
 	// ---- SHADE, first half: the direction before its normalisation
-	V3 pre = mk(0.0, 0.0, 1.0), view = pre, f0 = pre;
+	V3 pre, view, f0;
+	RMD_UNDEF(pre.x) RMD_UNDEF(pre.y) RMD_UNDEF(pre.z) RMD_UNDEF(view.x) RMD_UNDEF(view.y) RMD_UNDEF(view.z) RMD_UNDEF(f0.x) RMD_UNDEF(f0.y) RMD_UNDEF(f0.z)
 	bool diffuse = false;
-	double prob_d = 0.0, pdf_d = 0.0;
+	double prob_d, pdf_d;
+	RMD_UNDEF(prob_d) RMD_UNDEF(pdf_d)
 	if (do_shade) {
 		const V3 normal = in.normal;
 		view = normalize(cam_pos - in.frag); // :256

@@ -74,7 +74,7 @@ constexpr uint32_t kGridPersistWavesPerWg = RMD_GRID_PERSIST_WAVES; // ... of th
 // the spheres kernel's split launches (render_kernel.hpp: render_wave_sorted): path slots of a wave's pool and waves of a persistent workgroup —
 // 16 pools of 112 slots (86 bytes each) and the object table fit the CU's 160 KB
 #ifndef RMD_SORT_SLOTS
-#define RMD_SORT_SLOTS 112
+#define RMD_SORT_SLOTS 120
 #endif
 #ifndef RMD_SORT_WAVES
 #define RMD_SORT_WAVES 16 // waves of one persistent workgroup
@@ -82,7 +82,7 @@ constexpr uint32_t kGridPersistWavesPerWg = RMD_GRID_PERSIST_WAVES; // ... of th
 #ifndef RMD_SORT_WGS_PER_CU
 #define RMD_SORT_WGS_PER_CU 1 // persistent workgroups per CU (a workgroup holds at most 16 waves)
 #endif
-constexpr size_t kSortPoolBytes = 86u * RMD_SORT_SLOTS; // per-wave LDS (sizeof(SortPool))
+constexpr size_t kSortPoolBytes = 84u * RMD_SORT_SLOTS; // per-wave LDS (sizeof(HitStack): 9 doubles + 3 words an entry)
 // every wave's LDS area ends with 16 bytes of bookkeeping (render_kernel.hpp: word 0 = 1 + the work item a persistent wave drew last)
 constexpr size_t kWaveHeadBytes = 16u;
 // the form a render launch was made in (render_kernel.hpp: launch_render) -> rmd_launch_info

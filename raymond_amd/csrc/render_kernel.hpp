@@ -600,17 +600,17 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 // In render_wave() a lane keeps its path and every trip runs ONE merged instruction stream for the two things a lane may need — the
 // shading of the hit it carries, or the primary ray of its next sample.  With zero-throughput paths ended a sample is 2.13 path segments,
 // so 47 % of a trip's lanes start a sample and sit out the shading stream (331 of the trip's ~940 vector instructions) while the other
-// 53 % sit out ray generation: 68 % lane utilisation, measured.  Here the wave owns a POOL of kSortSlots path slots in LDS and a trip is
+// 53 % sit out ray generation: 68 % lane utilisation, measured.  Here the wave owns a STACK of up to kSortSlots parked hits in LDS and a trip is
 // one of two kinds, each with (up to) 64 lanes that all need the same thing:
-//   GI  64 empty slots take the work item's next 64 (pixel, sample) pairs: primary ray (src/trace.rs:322-333, thin lens :335-360),
-//       intersection, classification;
-//   SI  64 slots that hold a hit to shade: shading (:256-319) -> bounce ray, intersection, classification.
-// Classification (:242-252 and the rules of DESIGN.md section 3) ends a path — its sample goes to the per-sample buffer, its slot to the
-// empty list — or parks the hit in its slot (hit point, normal, throughput, RNG state: 9 doubles + 3 words) on the hit list.  A path's
-// arithmetic is the same functions in the same order as in render_wave(): every sample has the same bits; which lane and which trip
-// compute it changes nothing (the RNG is keyed by pixel and sample, the samples are added in order afterwards).  With
-// n_empty + n_hit = kSortSlots = 128 one of the two lists always holds 64 entries while the item has pairs left; when it runs out the
-// remaining hits are shaded in ever smaller trips (~3 of an item's ~120).
+//   GI  the work item's next 64 (pixel, sample) pairs, one per lane: primary ray (src/trace.rs:322-333, thin lens :335-360), intersection,
+//       classification;
+//   SI  the top 64 hits of the stack: shading (:256-319) -> bounce ray, intersection, classification.
+// Classification (:242-252 and the rules of DESIGN.md section 3) ends a path — its sample goes to the per-sample buffer — or parks the hit
+// (hit point, normal, throughput, RNG state: 9 doubles + 3 words) on the stack.  A path's arithmetic is the same functions in the same order
+// as in render_wave(): every sample has the same bits; which lane and which trip compute it changes nothing (the RNG is keyed by pixel and
+// sample, the samples are added in order afterwards).  A generation trip runs while the stack has room for the 64 hits it may park, so a
+// shading trip finds more than kSortSlots - 64 hits (56 of 64 lanes at 120 entries) until the item runs out of pairs; the remaining hits are
+// then shaded in ever smaller trips.
 #ifndef RMD_SORT_OBJ_PRIO
 #define RMD_SORT_OBJ_PRIO 1 // s_setprio level of the closest-hit loop over the objects in the role-sorted spheres kernel (0 = not raised)
 #endif
@@ -619,23 +619,29 @@ constexpr int kSortObjPrio = RMD_SORT_OBJ_PRIO;
 #define RMD_SORTED_TRIPS 1
 #endif
 constexpr uint32_t kSortSlots = RMD_SORT_SLOTS; // (launch.hpp)
-struct alignas(16) SortPool {
+// The wave's parked hits: a dense STACK in LDS (round 5; round 4 kept a path in a fixed slot of a pool and two lists of slot numbers).  A hit is
+// pushed where the stack ends — the lanes of a trip that park write to consecutive entries — and a shading trip pops the top 64, lane i entry
+// n_hit - 64 + i: every access of a trip is 64 consecutive 8-byte (or 4-byte) words, the one pattern the LDS serves without a bank conflict
+// (53 % of the LDS-active cycles of round 4's pool were conflicts: a trip's slot numbers were arbitrary), there are no slot lists to read and
+// write, and a lane that starts a sample needs no slot at all.
+struct alignas(16) HitStack {
 	double frag[3][kSortSlots], normal[3][kSortSlots], T[3][kSortSlots]; // the parked hit: point, surface normal; the path's throughput
 	uint32_t state[kSortSlots];     // object (16 bits) | next RNG block (16)
 	uint32_t lobe_bits[kSortSlots]; // the 22 spare bits of the path's last block | depth << 24
-	uint32_t item[kSortSlots]; // the path's (pixel, sample) pair: its number in the work item's pool
-	uint8_t empty_list[kSortSlots], hit_list[kSortSlots];
+	uint32_t item[kSortSlots];      // the path's (pixel, sample) pair: its number in the work item's pool
 };
-static_assert(kSortSlots >= 64u && kSortSlots <= 256u && kSortSlots % 8u == 0u, "slot numbers are bytes");
-static_assert(sizeof(SortPool) == kSortPoolBytes, "launch.hpp: kSortPoolBytes");
-// waves of a persistent workgroup of this kernel: 12 pools + the object table fit the CU's 160 KB (3 waves per SIMD; the kernel is
-// vector-ALU bound and times the same at 2 .. 5)
+static_assert(kSortSlots >= 72u && kSortSlots <= 512u && kSortSlots % 8u == 0u, "a generation trip needs room for 64 more hits");
+static_assert(sizeof(HitStack) == kSortPoolBytes, "launch.hpp: kSortPoolBytes");
+using SortPool = HitStack;
+// waves of a persistent workgroup of this kernel: 16 stacks + the object table fit the CU's 160 KB
 constexpr uint32_t kSortedWavesPerWg = RMD_SORT_WAVES;
 
+// A register pair the compiler may fill with anything: the value of a variable in the lanes that never use it.
+#define RMD_UNDEF3(v) RMD_UNDEF(v.x) RMD_UNDEF(v.y) RMD_UNDEF(v.z)
 RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_params, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids,
                                 const void *__restrict__ work, double *__restrict__ out, const DevObject *lobjs, unsigned char *wave_lds, uint32_t work_item) {
 	const uint32_t lane = threadIdx.x & 63u;
-	SortPool &pool = *reinterpret_cast<SortPool *>(wave_lds);
+	HitStack &stack = *reinterpret_cast<HitStack *>(wave_lds);
 	WalkScratch *no_scratch = nullptr; // (scene_intersect_wave<false> never touches it)
 	const uint32_t wt = work_item / P.split_k, part = work_item % P.split_k;
 	const bool have = wt < P.n_work;
@@ -647,17 +653,12 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 	if (P.bounce_limit == 0u) return; // (such launches are not made: api.cpp)
 	const V3 cam_pos = ld3(P.cam_pos);
 
-	// every slot starts empty
-	pool.empty_list[lane] = (uint8_t)lane;
-	if (lane + 64u < kSortSlots) pool.empty_list[lane + 64u] = (uint8_t)(lane + 64u);
-	uint32_t n_empty = kSortSlots, n_hit = 0, next_item = 0; // wave-uniform
-	// the trip loop's bound (report_fault): every trip hands out at least one pair or advances at least one path by a segment
+	uint32_t n_hit = 0, next_item = 0; // wave-uniform: entries on the stack, pairs handed out
+	// the trip loop's bound (report_fault): every trip hands out 64 pairs or advances at least one path by a segment
 	unsigned long long trips_left = (unsigned long long)pool_items * kTripBoundPerPair + 64ull;
 #if RMD_DIAG
 	if (P.debug_flags & 32u) trips_left = 1ull; // tests/test_gpu_faults.py: forces the bound
 #endif
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
 	for (;;) {
 		// the launch parameters a trip needs, re-read from the kernel arguments (see render_wave)
 #ifndef RMD_SORT_RELOAD
@@ -675,43 +676,45 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		const RenderParams &Pt = P;
 #endif
 
-		// which kind of trip: shade when 64 hits wait, else start samples while the item has any, else shade what is left.
-		// Every trip makes progress, for every pool size the static_assert admits (64 .. 256 slots).  Between trips n_empty + n_hit = kSortSlots
-		// >= 64: every slot a trip takes comes back to one of the two lists at its end.  A shading trip has min(n_hit, 64) lanes and is chosen
-		// when n_hit >= 64, or no pair is left (n_hit > 0 then, else the loop has ended), or n_empty < 64 and n_hit >= n_empty — then n_hit >=
-		// kSortSlots - 63 >= 1: at least one path advances by a segment, and a path has at most bounce_limit of them.  Otherwise pairs are left
-		// and n_empty >= 64 or n_empty > n_hit >= 0: the trip hands out min(n_empty, 64) >= 1 pairs (next_item grows).  There is no state in
-		// which a trip runs with no lane — unlike a pool with THREE lists, where all three can be short of a full trip while the empty list
-		// holds nothing (tools/experiments/README.md: the run that was killed for silence in round 4).
+		// Which kind of trip.  A generation trip (64 new samples) needs room for the 64 hits it may park: it runs while the item has pairs and
+		// the stack holds at most kSortSlots - 64 hits; else the top min(n_hit, 64) hits are shaded — more than kSortSlots - 64 of them (56 of 64
+		// lanes at 120 slots) unless the item has run out of pairs, when what is left is shaded in ever smaller trips.
+		// Every trip makes progress, for every stack size the static_assert admits: a generation trip hands out 64 pairs (next_item grows); a
+		// shading trip runs when no pair is left (n_hit > 0 then, else the loop has ended) or n_hit > kSortSlots - 64 >= 8, so at least one
+		// path advances by a segment, and a path has at most bounce_limit of them.  There is no state in which a trip runs with no lane —
+		// unlike a pool with THREE lists, where all three can be short of a full trip while the empty list holds nothing
+		// (tools/experiments/README.md: the run that was killed for silence in round 4).
 		if (trips_left-- == 0ull) { // (never reached: see above) — the wave reports, drops what it holds and leaves through the loop's own exit
 			report_fault(Pt, kFaultSortedTripLoop, work_item);
 			n_hit = 0u, next_item = pool_items;
 		}
 		const bool items_left = next_item < pool_items;
 		if (n_hit == 0u && !items_left) break;
-		// (a full trip of either kind when one list holds 64 slots — always, with 127 slots or more; else the longer list)
-		const bool shade_trip = n_hit >= 64u || !items_left || (n_empty < 64u && n_hit >= n_empty);
+		const bool shade_trip = !items_left || n_hit > kSortSlots - 64u;
 		bool active;
-		uint32_t slot = 0, item = 0, depth = 1;
+		uint32_t item = 0, depth = 1;
 		Rng rng;
 		rng.block = 0u, rng.lobe_bits = 0u;
-		V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1), T = mk(1.0, 1.0, 1.0);
+		// (no stand-in values for the lanes that sit a trip out: what such a lane holds is never stored, and a stand-in is a move per register and
+		// a select where the branches meet — 18 doubles a trip)
+		V3 ro, rd, T;
+		RMD_UNDEF3(ro) RMD_UNDEF3(rd) RMD_UNDEF3(T)
 		bool failed = false; // lens_failed / cut: the path ends with the sample T (.) 0
 		if (shade_trip) {
-			// ---------------- SI: the next (up to) 64 parked hits
+			// ---------------- SI: the top (up to) 64 parked hits, lane i the entry n_hit - n + i
 			const uint32_t n = n_hit < 64u ? n_hit : 64u;
 			active = lane < n;
-			slot = pool.hit_list[active ? n_hit - 1u - lane : 0u];
+			const uint32_t e = active ? n_hit - n + lane : 0u;
 			n_hit -= n;
-			const uint32_t st = pool.state[slot];
-			item = pool.item[slot];
-			const uint32_t lb = pool.lobe_bits[slot];
+			const uint32_t st = stack.state[e];
+			item = stack.item[e];
+			const uint32_t lb = stack.lobe_bits[e];
 			rng.block = st >> 16, rng.lobe_bits = lb & 0x3FFFFFu;
 			depth = lb >> 24;
 			const DevObject &o = lobjs[active ? (st & 0xFFFFu) : 0u];
-			T = mk(pool.T[0][slot], pool.T[1][slot], pool.T[2][slot]);
-			const V3 normal = mk(pool.normal[0][slot], pool.normal[1][slot], pool.normal[2][slot]);
-			const V3 frag = mk(pool.frag[0][slot], pool.frag[1][slot], pool.frag[2][slot]);
+			T = mk(stack.T[0][e], stack.T[1][e], stack.T[2][e]);
+			const V3 normal = mk(stack.normal[0][e], stack.normal[1][e], stack.normal[2][e]);
+			const V3 frag = mk(stack.frag[0][e], stack.frag[1][e], stack.frag[2][e]);
 			const uint32_t x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 			rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (item >> 6);
 			if (active) {
@@ -723,16 +726,12 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 			}
 		} else {
 			// ---------------- GI: the work item's next 64 (pixel, sample) pairs, one per lane (slots outside a ragged tile are skipped)
-			const uint32_t n = n_empty < 64u ? n_empty : 64u;
 			item = next_item + lane;
-			next_item += n;
-			active = lane < n && item < pool_items && (item & 7u) < tile.w && ((item >> 3) & 7u) < tile.h;
-			const unsigned long long am = __ballot(active);
-			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-			slot = pool.empty_list[active ? n_empty - 1u - rank : 0u];
-			n_empty -= (uint32_t)__popcll(am);
+			next_item += 64u;
+			active = item < pool_items && (item & 7u) < tile.w && ((item >> 3) & 7u) < tile.h;
 			const uint32_t x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 			rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (item >> 6);
+			T = mk(1.0, 1.0, 1.0);
 			if (active) {
 				double u0, u1;
 				rng.next2(Pt.key0, Pt.key1, u0, u1); // block 0: the pixel jitter (:326-327)
@@ -751,7 +750,8 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		if constexpr (kSortObjPrio != 0) __builtin_amdgcn_s_setprio(0);
 		// ---------------- classification (the rules of render_wave's phase C)
 		bool terminal = failed, park = false;
-		V3 L = mk(0.0, 0.0, 0.0), frag = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 1.0);
+		V3 L = mk(0.0, 0.0, 0.0), frag, normal;
+		RMD_UNDEF3(frag) RMD_UNDEF3(normal)
 		if (want) {
 			if (oi < 0) {
 				terminal = true; // :242 miss -> radiance 0
@@ -777,21 +777,18 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 			RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
 			store_sample(dst, L);
 		}
-		if (park) {
-			pool.frag[0][slot] = frag.x, pool.frag[1][slot] = frag.y, pool.frag[2][slot] = frag.z;
-			pool.normal[0][slot] = normal.x, pool.normal[1][slot] = normal.y, pool.normal[2][slot] = normal.z;
-			pool.T[0][slot] = T.x, pool.T[1][slot] = T.y, pool.T[2][slot] = T.z;
-			pool.state[slot] = (uint32_t)oi | (rng.block << 16); // (fewer than 2^16 objects fit the LDS; a lens loop runs at most 4096 rounds)
-			pool.lobe_bits[slot] = rng.lobe_bits | (depth << 24), pool.item[slot] = item;
-		}
-		// the slots go back: to the hit list or to the empty list
+		// the hits that go on: pushed onto the stack, consecutive entries for the lanes that park
 		{
-			const unsigned long long pm = __ballot(park), em = __ballot(active && !park);
-			const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-			const uint32_t erank = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-			if (park) pool.hit_list[n_hit + prank] = (uint8_t)slot;
-			if (active && !park) pool.empty_list[n_empty + erank] = (uint8_t)slot;
-			n_hit += (uint32_t)__popcll(pm), n_empty += (uint32_t)__popcll(em);
+			const unsigned long long pm = __ballot(park);
+			const uint32_t e = n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+			if (park) {
+				stack.frag[0][e] = frag.x, stack.frag[1][e] = frag.y, stack.frag[2][e] = frag.z;
+				stack.normal[0][e] = normal.x, stack.normal[1][e] = normal.y, stack.normal[2][e] = normal.z;
+				stack.T[0][e] = T.x, stack.T[1][e] = T.y, stack.T[2][e] = T.z;
+				stack.state[e] = (uint32_t)oi | (rng.block << 16); // (fewer than 2^16 objects fit the LDS; a lens loop runs at most 4096 rounds)
+				stack.lobe_bits[e] = rng.lobe_bits | (depth << 24), stack.item[e] = item;
+			}
+			n_hit += (uint32_t)__popcll(pm);
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
