@@ -153,6 +153,7 @@ def valu_block(name, avg_ms):
     # the fraction of the vector ALUs' issue slots this launch fills, and the fraction that does useful work (active lanes)
     v["valu_issue_frac"] = round(VALU_ISSUE_NS / v["simd_ns_per_valu_instr"], 4)
     v["useful_frac"] = round(v["valu_issue_frac"] * v["lane_utilisation"], 4)
+    # (v["wait"], when the profile holds it: SQ_WAIT_ANY / SQ_WAIT_INST_ANY per wave cycle and the LDS bank-conflict share, tools/profile_round.sh)
     if "valu_stream_ms" in v:
         # the launch's instruction stream priced class by class (f64 arithmetic 2.05 ns, rcp / rsq 6.7 ns, the rest 0.95 .. 1.28 ns per wave instruction
         # per SIMD: tools/microbench/valu_rate.hip) against this run's duration: how busy the vector ALUs are — valu_issue_frac prices every

@@ -609,7 +609,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 // (hit point, normal, throughput, RNG state: 9 doubles + 3 words) on the stack.  A path's arithmetic is the same functions in the same order
 // as in render_wave(): every sample has the same bits; which lane and which trip compute it changes nothing (the RNG is keyed by pixel and
 // sample, the samples are added in order afterwards).  A generation trip runs while the stack has room for the 64 hits it may park, so a
-// shading trip finds more than kSortSlots - 64 hits (56 of 64 lanes at 120 entries) until the item runs out of pairs; the remaining hits are
+// shading trip finds more than kSortSlots - 64 hits (57 .. 64 lanes at 120 entries) until the item runs out of pairs; the remaining hits are
 // then shaded in ever smaller trips.
 #ifndef RMD_SORT_OBJ_PRIO
 #define RMD_SORT_OBJ_PRIO 1 // s_setprio level of the closest-hit loop over the objects in the role-sorted spheres kernel (0 = not raised)
@@ -677,11 +677,14 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 #endif
 
 		// Which kind of trip.  A generation trip (64 new samples) needs room for the 64 hits it may park: it runs while the item has pairs and
-		// the stack holds at most kSortSlots - 64 hits; else the top min(n_hit, 64) hits are shaded — more than kSortSlots - 64 of them (56 of 64
-		// lanes at 120 slots) unless the item has run out of pairs, when what is left is shaded in ever smaller trips.
-		// Every trip makes progress, for every stack size the static_assert admits: a generation trip hands out 64 pairs (next_item grows); a
-		// shading trip runs when no pair is left (n_hit > 0 then, else the loop has ended) or n_hit > kSortSlots - 64 >= 8, so at least one
-		// path advances by a segment, and a path has at most bounce_limit of them.  There is no state in which a trip runs with no lane —
+		// the stack holds at most kSortSlots - 64 hits; else the top min(n_hit, 64) hits are shaded — more than kSortSlots - 64 of them (57 .. 64
+		// lanes at 120 entries) unless the item has run out of pairs, when what is left is shaded in ever smaller trips.  (RMD_SORT_FULL_SI = 1
+		// is the other way round — shading trips only when 64 hits wait, generation trips of min(64, kSortSlots - n_hit) pairs: measured 0.4 %
+		// slower on C2, 0.8 % with every path traced.)
+		// Every trip makes progress, for every stack size the static_assert admits: a generation trip hands out 64 pairs (kSortSlots - n_hit >= 9
+		// with RMD_SORT_FULL_SI) — next_item grows; a shading trip runs when no pair is left (n_hit > 0 then, else the loop has ended) or n_hit >
+		// kSortSlots - 64 >= 8 (>= 64), so at least one path advances by a segment, and a path has at most bounce_limit of them.  There is no
+		// state in which a trip runs with no lane —
 		// unlike a pool with THREE lists, where all three can be short of a full trip while the empty list holds nothing
 		// (tools/experiments/README.md: the run that was killed for silence in round 4).
 		if (trips_left-- == 0ull) { // (never reached: see above) — the wave reports, drops what it holds and leaves through the loop's own exit
@@ -690,7 +693,10 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		}
 		const bool items_left = next_item < pool_items;
 		if (n_hit == 0u && !items_left) break;
-		const bool shade_trip = !items_left || n_hit > kSortSlots - 64u;
+#ifndef RMD_SORT_FULL_SI
+#define RMD_SORT_FULL_SI 0
+#endif
+		const bool shade_trip = !items_left || (RMD_SORT_FULL_SI ? n_hit >= 64u : n_hit > kSortSlots - 64u);
 		bool active;
 		uint32_t item = 0, depth = 1;
 		Rng rng;
@@ -726,9 +732,10 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 			}
 		} else {
 			// ---------------- GI: the work item's next 64 (pixel, sample) pairs, one per lane (slots outside a ragged tile are skipped)
+			const uint32_t room = kSortSlots - n_hit, n = RMD_SORT_FULL_SI && room < 64u ? room : 64u;
 			item = next_item + lane;
-			next_item += 64u;
-			active = item < pool_items && (item & 7u) < tile.w && ((item >> 3) & 7u) < tile.h;
+			next_item += n;
+			active = lane < n && item < pool_items && (item & 7u) < tile.w && ((item >> 3) & 7u) < tile.h;
 			const uint32_t x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 			rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (item >> 6);
 			T = mk(1.0, 1.0, 1.0);

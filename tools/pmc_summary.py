@@ -78,6 +78,12 @@ if json_out:
                                               "vmem_read": c.get("SQ_INSTS_VMEM_RD", 0.0) / n, "smem": c.get("SQ_INSTS_SMEM", 0.0) / n}
                 valu[wl]["valu_stream_ms"] = {"low": (f64 * 2.05 + trans * 6.7 + other * 0.95) / N_SIMD * 1e-6, "high": (f64 * 2.05 + trans * 6.7 + other * 1.28) / N_SIMD * 1e-6,
                                               "how": "sum over instruction classes of count x measured issue cost / 1,024 SIMDs; low / high = the other-class cost of 0.95 / 1.28 ns"}
+            if "SQ_WAIT_ANY" in c and "SQ_LDS_BANK_CONFLICT" in c:
+                # where a wave's resident cycles go, and the LDS: bank-conflict cycles over the cycles the LDS is busy with this kernel's instructions
+                valu[wl]["wait"] = {"SQ_WAIT_ANY_per_wave_cycle": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "SQ_WAIT_INST_ANY_per_wave_cycle": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                                    "SQ_WAIT_INST_LDS_per_wave_cycle": c.get("SQ_WAIT_INST_LDS", 0.0) / c["SQ_WAVE_CYCLES"],
+                                    "LdsBankConflict_over_lds_active": c["SQ_LDS_BANK_CONFLICT"] / max(c.get("SQ_ACTIVE_INST_LDS", 0.0), 1.0),
+                                    "LdsBankConflict_over_lds_idx_active": c["SQ_LDS_BANK_CONFLICT"] / max(c.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0)}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             fetch = c["FETCH_SIZE"] + c.get("FETCH_SIZE[sum_kernel]", 0.0)
             write = c["WRITE_SIZE"] + c.get("WRITE_SIZE[sum_kernel]", 0.0)
