@@ -222,7 +222,10 @@ enum {
 	                              walks to the wave's next call (0 = the library's choice, K = 4; 1 = every call finishes every walk)      */
 	RMD_TUNE_SPLIT_MIN_SAMPLES = 6, /* RMD_SPLIT_MIN_SAMPLES: fewest samples per pixel a work item of a split launch may hold (0 = the library's
 	                              choice: 4 in scenes with grids — two items per wave tile from 4 samples per pixel on — 64 without)      */
-	RMD_TUNE_COUNT = 7
+	RMD_TUNE_CHAIN_ITEMS = 7,  /* RMD_CHAIN_ITEMS: split launches of scenes with grids whose persistent waves draw their next work item while the last
+	                              paths of the current one finish: 0 = the library's choice (launches of at most 96 samples per pixel), 1 = never,
+	                              2 = always                                                                                                  */
+	RMD_TUNE_COUNT = 8
 };
 /* Free and total memory of the context's device, bytes (hipMemGetInfo): what a host that shares the GPU sizes its launches by. */
 rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, uint64_t *out_total_bytes);
@@ -298,7 +301,8 @@ typedef struct rmd_launch_info {
 	uint32_t waves_per_workgroup; /* waves of a workgroup of the last pass (persistent form: 16 unless the LDS left room for fewer) */
 	uint32_t buffered;        /* 1 = the pooled (pixel, sample) hand-out + per-sample scratch + ordered sum ran (split_k > 1, or one item per
 	                             wave tile: short launches of scenes with grids), 0 = direct mode (lane = pixel, no scratch)               */
-	uint32_t _pad[1];
+	uint32_t chained;         /* 1 = persistent waves drew their next work item while the last paths of the current one finished (short
+	                             split launches of scenes with grids; RMD_TUNE_CHAIN_ITEMS)                                                */
 } rmd_launch_info;
 rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out);
 

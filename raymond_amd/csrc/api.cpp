@@ -68,6 +68,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_SCRATCH_CAP_MB] = env_int("RMD_SCRATCH_CAP_MB");
 		ctx->tunable[RMD_TUNE_WALK_CUT] = env_int("RMD_WALK_CUT");
 		ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] = env_int("RMD_SPLIT_MIN_SAMPLES");
+		ctx->tunable[RMD_TUNE_CHAIN_ITEMS] = env_int("RMD_CHAIN_ITEMS");
 		const char *form = std::getenv("RMD_LAUNCH_FORM");
 		ctx->tunable[RMD_TUNE_LAUNCH_FORM] = !form ? 0 : (std::strcmp(form, "per-item") == 0 || std::strcmp(form, "1") == 0) ? 1 : (std::strcmp(form, "persistent") == 0 || std::strcmp(form, "2") == 0) ? 2 : 0;
 #if RMD_DIAG
@@ -627,7 +628,8 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 		const uint32_t waves_per_slot = has_grid ? 64u : 24u;
 		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
-		uint32_t min_samples = has_grid ? rmd::kSplitMinSamplesGrid : 64u;
+		// (launches short enough for the instantiation whose waves chain their work items — an item's end costs them nothing — take items of 2)
+		uint32_t min_samples = has_grid ? (sample_count <= rmd::kChainMaxSamples && ctx->tunable[RMD_TUNE_CHAIN_ITEMS] != 1 ? 2u : rmd::kSplitMinSamplesGrid) : 64u;
 		if (ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] > 0) min_samples = (uint32_t)std::min<int64_t>(ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES], 1 << 20);
 		if (k > sample_count / min_samples) k = sample_count / min_samples;
 		// ... but two items per wave tile while each still holds two samples (C3 at 4 spp: 4.5 ms as two items of 2 samples, 5.1 as one item of 4:
@@ -684,6 +686,9 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			cap = (free_b + ctx->sample_buf_bytes) / 8; // the buffer this context already holds counts as available to it
 		}
 		if (bytes_per_sample * per_pass > cap) per_pass = (uint32_t)(cap / bytes_per_sample);
+		// (the mesh kernel numbers a pass's 32-byte sectors in 32 bits: render_kernel.hpp, PathId)
+		const uint64_t sectors_per_sample = (uint64_t)P.n_work * 64u;
+		if (sectors_per_sample * per_pass > 0xFFFFFFFFull) per_pass = (uint32_t)(0xFFFFFFFFull / sectors_per_sample);
 		if (per_pass < 8u) per_pass = 8u;
 		if (per_pass > P.sample_count) per_pass = P.sample_count;
 		while (bytes_per_sample * per_pass > ctx->sample_buf_bytes) {
@@ -712,6 +717,10 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		Q.sample_count = settings->sample_count - done < per_pass ? (uint32_t)(settings->sample_count - done) : per_pass;
 		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
 		Q.buffered = buffered ? 1u : 0u;
+		{ // short launches chain their work items (launch.hpp: kChainMaxSamples; RMD_TUNE_CHAIN_ITEMS: 1 = never, 2 = always)
+			const int64_t force = ctx->tunable[RMD_TUNE_CHAIN_ITEMS];
+			Q.chain_items = (buffered && scene->n_grids != 0u && (force == 2 || (force == 0 && Q.sample_count <= rmd::kChainMaxSamples))) ? 1u : 0u;
+		}
 		Q.sample_buf = ctx->d_sample_buf;
 		// (a launch with fewer work items than the device has wave slots spreads better as one wave per item)
 		const bool persistent_pass = persistent && ((uint64_t)P.n_work * Q.split_k >= ctx->wave_slots || ctx->tunable[RMD_TUNE_LAUNCH_FORM] == 2);
@@ -736,6 +745,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent_pass ? ctx->n_cus : 0u, &shape));
 		ctx->last_launch.passes++, ctx->last_launch.split_k = Q.split_k, ctx->last_launch.buffered = Q.buffered;
 		ctx->last_launch.persistent = shape.persistent, ctx->last_launch.waves_per_workgroup = shape.waves_per_wg; // the form it was launched in, not the one asked for
+		ctx->last_launch.chained = shape.persistent ? Q.chain_items : 0u;
 		if (settings->sample_count == 0) break;
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));

@@ -109,6 +109,9 @@ struct RenderParams {
 	uint32_t shade_last_depth;          // 1: the hit at the bounce limit is shaded although its result is its weight times the zero the recursive call returns
 	                                    // (src/trace.rs:235-237) — a scene outside the regular parameter class (api.cpp: rmd_scene::regular), where that weight can be
 	                                    // NaN with finite inputs (roughness 0: 0 / 0 in geometry_schlick_ggx) and the reference's sample NaN x 0 = NaN
+	uint32_t chain_items;               // 1: persistent waves of a split launch of a scene with grids draw their next work item while the last paths of the current one
+	                                    // finish (render_kernel.hpp: render_wave, CHAIN) — launches of few samples per pixel, where an item's drain is a fifth of it
+	uint32_t _pad1;
 	uint32_t buffered;                  // 1: the tiles-buffered instantiation (pooled (pixel, sample) hand-out, per-sample scratch, ordered sum) — also with split_k = 1
 	uint32_t *fault;                    // the context's fault words (host memory mapped into the device's address space; kFault*): a wave whose loop runs past
 	                                    // its bound reports here, poisons work_counter so that the launch drains, and leaves (render_kernel.hpp: report_fault)

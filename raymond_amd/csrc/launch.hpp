@@ -53,6 +53,11 @@ constexpr uint32_t kSplitMinSamplesGrid = RMD_SPLIT_MIN_SAMPLES_GRID;
 #define RMD_SORTED_MIN_SAMPLES 128
 #endif
 constexpr uint32_t kSortedMinSamples = RMD_SORTED_MIN_SAMPLES;
+// split launches of scenes with grids of at most this many samples per pixel run the instantiation whose waves chain their work items
+#ifndef RMD_CHAIN_MAX_SAMPLES
+#define RMD_CHAIN_MAX_SAMPLES 96
+#endif
+constexpr uint32_t kChainMaxSamples = RMD_CHAIN_MAX_SAMPLES;
 // walks put aside (grid_walk.hpp: cut_lanes): a walk call leaves its last K walkers to the wave's next call
 constexpr uint32_t kWalkCutDefault = 4;
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)

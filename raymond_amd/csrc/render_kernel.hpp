@@ -14,7 +14,13 @@ namespace rmd {
 // per-wave LDS of the grid kernel: the walk scratch and the 64 paths' throughput (3 doubles per lane)
 // ... and the DDA states of walks put aside for the wave's next walk call (grid_walk.hpp: WalkCarry)
 // ... and the wave's 16 bytes of bookkeeping behind them (launch.hpp: kWaveHeadBytes)
-__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return kWaveHeadBytes + (n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) + sizeof(WalkCarry) : 0); }
+// ... and, per lane, which (pixel, sample) its path belongs to: PathId (a wave's lanes may hold paths of two work items: render_wave, CHAIN)
+struct alignas(16) PathId {
+	uint32_t px[64];     // x | y << 16
+	uint32_t smp[64];    // the sample's index (sample_begin included)
+	uint32_t sector[64]; // the sample's 32-byte sector in the per-sample scratch
+};
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t n_grids) { return kWaveHeadBytes + (n_grids ? sizeof(WalkScratch) + 64u * 3u * sizeof(double) + sizeof(WalkCarry) + sizeof(PathId) : 0); }
 
 // Block -> work item mapping.  Workgroups are dealt round-robin over the 8 XCDs, and host tiles arrive in the
 // reference's column-major order, so consecutive work items are vertical neighbours.  Plain order (block b -> item b)
@@ -201,10 +207,16 @@ RMD_DEV void finish_sample_range(const RenderParams &P, const WaveTile &tile, ui
 // sub-range).  Called by all 64 lanes of a wave in uniform control flow; lobjs / lds_masks / wave_lds are the workgroup's staged
 // object table and occupancy masks and this wave's scratch in LDS.
 typedef const __attribute__((address_space(4))) unsigned long long *KernargWords; // the kernel-argument segment, as 8-byte words
-template <int MODE, bool GRID>
+// CHAIN (split launches of scenes with grids, persistent form): the wave does not end with its work item.  When the item's pool of (pixel,
+// sample) pairs has run dry it DRAWS THE NEXT ITEM itself and goes on handing out pairs while the last paths of the old item finish — an item
+// used to end with a drain of ~7 trips of ever fewer lanes (2 % of a 55-sample item's trips, 20 % of a 4-sample item's: a progressive pass).
+// A path's identity — pixel, sample, scratch sector — therefore lives per lane (PathId, in LDS), not in wave-uniform item state.  Which lane
+// and which trip compute a sample changes nothing: same bits.
+template <int MODE, bool GRID, bool CHAIN = false>
 RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids,
                          const void *__restrict__ work, double *__restrict__ out, int32_t *__restrict__ path_obj, uint32_t *__restrict__ path_sub,
                          const DevObject *lobjs, const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first) {
+	static_assert(!CHAIN || (MODE == kModeTilesBuffered && GRID), "items are chained in split launches of scenes with grids");
 	constexpr bool LIST = MODE == kModeList;
 	const uint32_t lane = threadIdx.x & 63u;
 	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds); // unused (and not allocated) when the scene has no grid
@@ -221,7 +233,9 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 	uint32_t list_idx = 0;
 	WaveTile tile = {};
 	uint32_t wt = 0, pool_first = 0, pool_items = 0, next_item = 0; // wave-uniform (buffered mode)
-	uint32_t item = 0;                                               // this lane's pool item (buffered mode)
+	uint32_t item = 0;                                               // this lane's pool item (buffered mode without a grid)
+	constexpr bool id_in_lds = to_buffer && GRID;                    // ... with a grid: the path's identity in LDS (PathId)
+	[[maybe_unused]] PathId *pid = GRID ? reinterpret_cast<PathId *>(wave_lds + sizeof(WalkScratch) + 64u * 3u * sizeof(double) + sizeof(WalkCarry)) : nullptr;
 	if (LIST) {
 		list_idx = first + lane;
 		alive = list_idx < P.n_work;
@@ -360,6 +374,38 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			}
 		};
 		decltype(auto) Pt = trip_params();
+		if constexpr (CHAIN) {
+			// the item's pool has run dry: the wave draws its next work item (the persistent work loop's draw, render_kernel below, with the same
+			// bound: a draw must be larger than the wave's last).  pool_items = 0xFFFFFFFF marks "the launch has no item left".
+			if (next_item >= pool_items && pool_items != 0xFFFFFFFFu) {
+				volatile uint32_t *last_draw = reinterpret_cast<volatile uint32_t *>(wave_lds + wave_lds_bytes(1u) - kWaveHeadBytes);
+				uint32_t drawn = 0, floor = 0;
+				if (lane == 0u) {
+					drawn = atomicAdd(Pt.work_counter, 1u);
+					floor = *last_draw;
+					*last_draw = drawn + 1u;
+				}
+				drawn = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+				floor = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor);
+#if RMD_DIAG
+				if ((Pt.debug_flags & 128u) && floor != 0u) floor = 0xFFFFFFFFu; // tests/test_gpu_faults.py: forces the bound at a wave's second draw
+#endif
+				if (drawn >= Pt.n_work * Pt.split_k) {
+					pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
+				} else {
+#if RMD_BOUND_DRAWS
+					if (drawn < floor) report_fault(Pt, kFaultWorkLoop, drawn); // (never reached; the poisoned counter ends the launch)
+#endif
+					wt = drawn / Pt.split_k;
+					const uint32_t part = drawn - wt * Pt.split_k;
+					tile = reinterpret_cast<const WaveTile *>(work)[wt];
+					const uint32_t per_part = (Pt.sample_count + Pt.split_k - 1u) / Pt.split_k;
+					const uint32_t s_lo = part * per_part < Pt.sample_count ? part * per_part : Pt.sample_count;
+					const uint32_t s_hi = s_lo + per_part < Pt.sample_count ? s_lo + per_part : Pt.sample_count;
+					pool_first = s_lo, pool_items = (s_hi - s_lo) * 64u, next_item = 0u;
+				}
+			}
+		}
 #if RMD_BOUND_TRIPS
 		// (no `break` here: a second way out of this loop cost the mesh kernel 40 spilled registers.  A stalled wave reports, drops every path
 		// and pair it holds and leaves through the loop's own exit below.)
@@ -368,7 +414,8 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		if (stalled) {
 			report_fault(Pt, kFaultTripLoop, first);
 			complete = false, lens_failed = false, cut = false, has_ray = false, to_shade = false, need_sample = false, alive = false;
-			if constexpr (to_buffer) next_item = pool_items;
+			if constexpr (CHAIN) pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
+			else if constexpr (to_buffer) next_item = pool_items;
 			else s = s_end;
 		}
 #endif
@@ -433,7 +480,9 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			if constexpr (to_buffer) {
 				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
 				// sample's store travels alone, and a 24-byte store that straddles sectors was costing 2.7x its size in L2 write-backs
-				RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
+				RMD_GLOBAL double *dst;
+				if constexpr (id_in_lds) dst = (RMD_GLOBAL double *)Pt.sample_buf + (size_t)pid->sector[lane] * kSampleStride;
+				else dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
 				// plain stores: when a wave of this kernel adds the tile's samples (below) — it may run on another XCD, whose L2 does not see this
 				// one's dirty lines — the release in front of the tile's counter writes them back, once per work item (round 2 wrote every
 				// sample through with three 8-byte agent-scope stores: 96 bytes at the memory side per 24-byte sample)
@@ -462,12 +511,20 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 				const uint32_t k = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				next_item += (uint32_t)__popcll(idle);
 				trips_since_walk &= 0xFFu; // pairs handed out: the stall watch starts again
-				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) // slots outside a ragged tile are skipped
-					item = k, prim = true;
+				if (need_sample && k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h) { // slots outside a ragged tile are skipped
+					prim = true;
+					if constexpr (id_in_lds) { // the path's identity: pixel, sample, scratch sector of the pair it was handed
+						pid->px[lane] = (uint32_t)(tile.x0 + (k & 7u)) | (uint32_t)(tile.y0 + ((k >> 3) & 7u)) << 16;
+						pid->smp[lane] = Pt.sample_begin + pool_first + (k >> 6);
+						pid->sector[lane] = (wt * Pt.sample_count + pool_first + (k >> 6)) * 64u + (k & 63u); // (< 2^32: api.cpp caps a pass)
+					} else {
+						item = k;
+					}
+				}
 			}
 			alive = prim || has_ray || to_shade;
 			if (__ballot(alive) == 0ull) {
-				if (next_item >= pool_items) break;
+				if (next_item >= pool_items && (!CHAIN || pool_items == 0xFFFFFFFFu)) break;
 				complete = false, cut = false, lens_failed = false; // (C) has consumed them: the next pass through it must not classify a hit twice
 				continue; // a handout that fell entirely on slots outside the tile
 			}
@@ -486,7 +543,10 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		}
 		// pixel and sample of the lane's path: in a split launch they are functions of the pool item (one integer of state per
 		// lane; kept as x, y, s they were spilled to scratch at every hand-out), otherwise the lane's own
-		if constexpr (to_buffer) {
+		if constexpr (id_in_lds) {
+			const uint32_t pxv = pid->px[lane];
+			x = pxv & 0xFFFFu, y = pxv >> 16, s = pid->smp[lane];
+		} else if constexpr (to_buffer) {
 			x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 			s = Pt.sample_begin + pool_first + (item >> 6);
 		} else if constexpr (acc_in_memory) {
@@ -810,12 +870,17 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 // 4-wave workgroup, which leaves each wave 8 KB of LDS, and no wave slot idles while the rest of a workgroup finishes.
 template <int MODE, bool GRID>
 constexpr bool kSortedTrips = RMD_SORTED_TRIPS && MODE == kModeTilesBuffered && !GRID;
+#ifndef RMD_CHAIN_ITEMS
+#define RMD_CHAIN_ITEMS 1
+#endif
+template <int MODE, bool GRID>
+constexpr bool kChainItems = RMD_CHAIN_ITEMS && MODE == kModeTilesBuffered && GRID; // (persistent form only: render_wave, CHAIN)
 // LDS of one wave of an instantiation
 template <int MODE, bool GRID>
 __host__ __device__ inline size_t wave_lds_of(uint32_t n_grids) { return kSortedTrips<MODE, GRID> ? kWaveHeadBytes + sizeof(SortPool) : wave_lds_bytes(n_grids); }
 template <int MODE, bool GRID>
 constexpr uint32_t kPersistWaves = kSortedTrips<MODE, GRID> ? kSortedWavesPerWg : GRID ? kGridPersistWavesPerWg : kPersistWavesPerWg;
-template <int MODE, bool GRID, bool PERSIST>
+template <int MODE, bool GRID, bool PERSIST, bool CHAIN = false>
 __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ? 64 * kGridWavesPerWg : 64,
                              GRID ? RMD_GRID_MINW : (kSortedTrips<MODE, GRID>) ? (RMD_SORT_WAVES * RMD_SORT_WGS_PER_CU / 4) : (PERSIST ? 4 : RMD_NOGRID_MINW)) void render_kernel(
     RenderParams P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work, double *__restrict__ out,
@@ -877,7 +942,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ?
 			}
 #endif
 			if constexpr (kSortedTrips<MODE, GRID>) render_wave_sorted(P, kernarg_params, objs, grids, work, out, lobjs, wave_lds, item);
-			else render_wave<MODE, GRID>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
+			else render_wave<MODE, GRID, CHAIN>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
 		}
 	} else {
 		const uint32_t unit = work_item_of_block(blockIdx.x, gridDim.x) * waves_per_wg + wave;
@@ -904,12 +969,19 @@ inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const
 		while (pw > 4u && lds_for(pw) > kLdsBudgetBytes) pw--;
 		if (n_cus != 0u && P.work_counter != nullptr && lds_for(pw) <= kLdsBudgetBytes) {
 			const size_t lds = lds_for(pw);
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-			                                   (int)kLdsBudgetBytes);
+			// short launches of scenes with grids: the instantiation whose waves chain their work items (render_wave, CHAIN)
+			const bool chain = kChainItems<MODE, GRID> && P.chain_items != 0u;
+			hipError_t e = hipFuncSetAttribute(chain ? reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true, (kChainItems<MODE, GRID>)>)
+			                                         : reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>),
+			                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
 			if (e != hipSuccess) return e;
 			const uint32_t wgs = (n_waves + pw - 1u) / pw, resident = n_cus * (kSortedTrips<MODE, GRID> ? RMD_SORT_WGS_PER_CU : 1u);
-			hipLaunchKernelGGL((render_kernel<MODE, GRID, true>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs, grids, work, out,
-			                   path_obj, path_sub);
+			if (chain)
+				hipLaunchKernelGGL((render_kernel<MODE, GRID, true, (kChainItems<MODE, GRID>)>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs,
+				                   grids, work, out, path_obj, path_sub);
+			else
+				hipLaunchKernelGGL((render_kernel<MODE, GRID, true>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs, grids, work, out,
+				                   path_obj, path_sub);
 			if (shape) shape->persistent = 1u, shape->waves_per_wg = pw;
 			return hipGetLastError();
 		}

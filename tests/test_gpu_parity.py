@@ -1047,6 +1047,44 @@ def test_walks_put_aside_do_not_change_the_image(gpu_ctx, small_mesh_scene):
     fb.close(), ds.close()
 
 
+def test_chained_work_items_do_not_change_the_image(gpu_ctx, small_mesh_scene, oracle):
+    """Short split launches of scenes with grids run the instantiation whose persistent waves draw their next work item while the last paths of
+    the current one finish (render_kernel.hpp: render_wave, CHAIN; a path's pixel, sample and scratch sector live per lane).  Which lane, trip and
+    wave compute a sample changes nothing: chained, unchained and direct launches give the same frame bit for bit — ragged tiles, thin lens,
+    several passes of the scratch, any split — and the oracle's."""
+    W, H = 203, 117
+    tiles = generate_tiles(W, H, (32, 32))
+    ds = render.DeviceScene(gpu_ctx, small_mesh_scene)
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    for spp, dof, bounces in ((12, False, 5), (40, True, 8), (3, False, 2)):
+        st = Settings(scenes.camera(W, H, aperture_radius=0.4 if dof else 0.0), sample_count=spp, bounce_limit=bounces, seed=77, use_dof=dof)
+        frames = {}
+        for name, chain, split, cap in (("chained", 2, 0, 0), ("unchained", 1, 0, 0), ("chained-many-items", 2, 5, 0), ("chained-two-passes", 2, 0, 1), ("direct", 1, 1, 0)):
+            gpu_ctx.set_tunable(abi.RMD_TUNE_CHAIN_ITEMS, chain), gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
+            gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, cap), gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, 2)
+            try:
+                fb.zero()
+                render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
+                info = gpu_ctx.last_launch_info()
+                frames[name] = fb.download()
+                if name == "chained-many-items" and spp < 8:
+                    assert info.buffered == 0  # (a forced split keeps 4 samples per item: 3 samples run in direct mode)
+                elif name.startswith("chained"):
+                    assert info.chained == 1 and info.persistent == 1 and info.buffered == 1, (name, info.chained, info.persistent)
+                else:
+                    assert info.chained == 0
+                if name == "chained-two-passes" and spp >= 16:
+                    assert info.passes >= 2
+            finally:
+                for key in (abi.RMD_TUNE_CHAIN_ITEMS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_SCRATCH_CAP_MB, abi.RMD_TUNE_LAUNCH_FORM):
+                    gpu_ctx.set_tunable(key, 0)
+        for name, img in frames.items():
+            assert same_bits(img, frames["direct"]).all(), (spp, name)
+        ref = oracle.OracleScene(small_mesh_scene).render_tiles(st.camera_settings, st, tiles, threads=8)
+        assert rel_close(frames["chained"], ref, 1e-9).all(axis=2).mean() >= 0.995
+    fb.close(), ds.close()
+
+
 def test_walk_batching_does_not_change_the_image(gpu_ctx, small_mesh_scene):
     """Grid scenes: a lane whose ray enters a grid's box waits until enough lanes of its wave need a walk (kernels.hip,
     RenderParams::walk_batch).  That is scheduling only — the closest hit is the lexicographic minimum of (distance,
