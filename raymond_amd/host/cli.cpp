@@ -25,9 +25,12 @@ using namespace raymond;
 // A consumer of a progressive render: every message through poll() (src/trace.rs:115-117) as it arrives — TileProgressed snapshots are counted,
 // TileFinished tiles are assembled into the image as await() would (:93-99).  (await() itself stops collecting at the first message that is not
 // TileFinished, :101-103: with snapshots of several workers in the channel it is only safe once they have been drained.)
-static std::vector<Vector3> consume(TaskHandle &handle, const Settings &st, size_t &progressed) {
+static std::vector<Vector3> consume(TaskHandle &handle, const Settings &st, size_t &progressed, double *last_finished_s = nullptr,
+                                    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now()) {
 	const size_t W = st.camera_settings.backbuffer_width, H = st.camera_settings.backbuffer_height;
-	std::vector<Vector3> image(W * H, Vector3{0, 0, 0});
+	const size_t n_tiles = generate_tiles(W, H, st.tile_size).size();
+	std::vector<Tile> finished_tiles; // (zero-copy views of the download's block: taking them is cheap; the image is assembled afterwards)
+	finished_tiles.reserve(n_tiles);
 	for (;;) {
 		const bool done = handle.finished(); // read BEFORE the channel is drained: nothing is sent after the last worker has left
 		while (std::optional<Message> m = handle.poll()) {
@@ -35,18 +38,21 @@ static std::vector<Vector3> consume(TaskHandle &handle, const Settings &st, size
 				progressed++;
 				continue;
 			}
-			const Tile &t = m->tile;
-			for (size_t y = 0; y < t.height; y++)
-				for (size_t x = 0; x < t.width; x++) {
-					Vector3 v = t.data[x + y * t.width];
-					for (double &c : v) c /= (double)t.sample_count; // :95
-					image[x + t.left + (y + t.top) * W] = v;
-				}
+			finished_tiles.push_back(std::move(m->tile));
+			if (finished_tiles.size() == n_tiles && last_finished_s) *last_finished_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		}
-		if (done) break;
-		std::this_thread::sleep_for(std::chrono::microseconds(200));
+		if (done || finished_tiles.size() == n_tiles) break;
+		std::this_thread::sleep_for(std::chrono::microseconds(100));
 	}
-	handle.await(); // joins nothing new: every worker has left; rethrows a worker's error
+	std::vector<Vector3> image(W * H, Vector3{0, 0, 0});
+	for (const Tile &t : finished_tiles)
+		for (size_t y = 0; y < t.height; y++)
+			for (size_t x = 0; x < t.width; x++) {
+				Vector3 v = t.data[x + y * t.width];
+				for (double &c : v) c /= (double)t.sample_count; // :95
+				image[x + t.left + (y + t.top) * W] = v;
+			}
+	handle.await(); // waits for the workers to leave (they free their device memory after their last message); rethrows a worker's error
 	return image;
 }
 
@@ -131,17 +137,10 @@ int main(int argc, char **argv) {
 				progressed = 0;
 				const auto t0 = std::chrono::steady_clock::now();
 				TaskHandle handle = render_tiled(scene, st);
-				// wall: call -> the last TileFinished message has been sent (the last worker has left); await: ... -> the image is assembled (:93-99)
+				// wall: call -> the last TileFinished message has ARRIVED at the consumer (every message taken through poll() as it comes); then the
+				// image is assembled as await() would (:93-99) and the workers' teardown is waited for
 				double secs = 0.0;
-				std::vector<Vector3> image;
-				if (st.samples_per_iteration) {
-					image = consume(handle, st, progressed);
-					secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-				} else {
-					while (!handle.finished()) std::this_thread::sleep_for(std::chrono::microseconds(100));
-					secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-					image = handle.await();
-				}
+				std::vector<Vector3> image = consume(handle, st, progressed, &secs, t0);
 				const double secs_await = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 				if (secs < best) best = secs, best_setup = handle.setup_seconds(), best_await = secs_await;
 				checksum = 0.0;
