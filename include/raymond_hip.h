@@ -142,10 +142,17 @@ typedef struct rmd_camera {
  * radiance, because 0 x NaN = NaN.  The one source of such a vertex is the interpolated normal of a mesh hit (triangle.rs:47-68: Heron's
  * radicand rounding below zero for a hit on an edge, or vertex normals that sum to zero); a scene of planes and spheres has none.
  *
- *   flags = 0 (default)               REFERENCE-IDENTICAL on every scene.  Such paths are ended early exactly where that cannot change a
- *                                     sample: in scenes WITHOUT grid objects.  In a scene with a grid they are traced to their end, as
- *                                     the reference does, so a sample that is NaN in the reference is NaN here.  This is what a drop-in
- *                                     caller gets (integration/gpu.rs).
+ *   flags = 0 (default)               REFERENCE-IDENTICAL on every scene.  Such paths are ended early only where that is PROVED not to
+ *                                     change a sample: in scenes WITHOUT grid objects whose parameters are all REGULAR — every coordinate,
+ *                                     colour and radiance finite and at most 1e150 in magnitude, no sphere of radius 0, no material of
+ *                                     roughness 0 (rmd_scene_create decides this once per scene).  Everywhere else — a scene with a grid,
+ *                                     or a grid-less scene outside that class: an Emission((inf, 0, 0)) behind a black bounce is
+ *                                     0 x inf = NaN, roughness 0 makes geometry_schlick_ggx 0 / 0 (:372-378) — every path is traced to its
+ *                                     end, the last depth included, as the reference does, so a sample that is NaN in the reference is NaN
+ *                                     here (tests/test_gpu_parity.py::test_flags_0_is_reference_identical_for_non_finite_scene_parameters).
+ *                                     What is NOT covered: events of probability ~2^-53 per path inside the regular class (r1 = 0 exactly
+ *                                     in a diffuse pdf, a bounce ray exactly opposite to the view vector).
+ *                                     This is what a drop-in caller gets (integration/gpu.rs).
  *   RMD_RENDER_END_BLACK_PATHS        opt-in, scenes with grids: end such paths there too.  Every sample that is finite in the reference
  *                                     keeps its value bit for bit; a sample the reference makes NaN behind a zero weight comes out (0, 0, 0)
  *                                     (how many pixels of the benchmark frames that is: DESIGN.md section 3, counted on the GPU).  A
