@@ -45,19 +45,42 @@ RMD_DEV V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
 RMD_DEV V3 hadamard(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 RMD_DEV double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; } // cgmath: mul_element_wise().sum()
 RMD_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-// IEEE square root.  The compiler's expansion of sqrt(double) pre-scales arguments below 2^-767 (compare, two selects,
-// two ldexp around the refinement); no length, discriminant or area on this path is ever that small, so when no lane of
-// the wave holds such an argument (one ballot) the same refinement runs without the scaling — identical operations on
-// identical values, hence identical results — and otherwise the wave takes the compiler's sequence.
+// IEEE square root.  The compiler's expansion of sqrt(double) pre-scales arguments below 2^-767 (compare, two selects, two ldexp around the
+// refinement) and ends with a select that returns +-0 and +inf unchanged (class compare, two selects); no length, discriminant or area on this
+// path is that small, zero or infinite in the ordinary course, so when every lane of the wave holds a finite argument >= 2^-767 — ONE unsigned
+// range test on the high word: 0x10000000 <= hi < 0x7FF00000 excludes small, zero, negative, infinite and NaN arguments alike — the same
+// refinement runs without the scaling and without the final select: identical operations on identical values, hence identical results
+// (tools/microbench: 0 mismatches in 3.4e11 arguments).  Otherwise (one ballot) the whole wave takes the compiler's sequence.
+// RMD_SQRT_RANGE_TEST: 1 = this form (two integer instructions of special-casing per root); 0 = round 4's (two f64 compares in front for the small
+// arguments, the class select behind: five instructions, three of them at the price of an f64 addition each — tools/microbench/valu_rate.hip);
+// 2 = one integer compare in front, the select behind.  Measured with the branch-free object tests (C2 / every path traced / C3 / C3 with black
+// paths ended): 49.0 / 86.9 / 418.0 / 263.2 ms with 0, 49.0 / 86.0 / 410.5 / 260.2 with 1, 49.0 / 86.8 / 417.1 / 262.8 with 2.
+#ifndef RMD_SQRT_RANGE_TEST
+#define RMD_SQRT_RANGE_TEST 1
+#endif
 RMD_DEV double sqrt64(double x) {
+#if RMD_SQRT_RANGE_TEST == 1
+	const uint32_t hi = (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32);
+	if (__ballot(hi - 0x10000000u >= 0x7FF00000u - 0x10000000u) != 0ull) return __builtin_sqrt(x);
+#elif RMD_SQRT_RANGE_TEST == 2
+	// +0 and positive arguments below 2^-767 as ONE unsigned compare of the high word (an f64 compare costs as much as an f64 addition, an integer
+	// one half: tools/microbench/valu_rate.hip); negative, infinite and NaN arguments take the refinement as before
+	const uint32_t hi = (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32);
+	if (__ballot(hi < 0x10000000u) != 0ull) return __builtin_sqrt(x);
+#else
 	if (__ballot(x < 0x1p-767 && x > 0.0) != 0ull) return __builtin_sqrt(x);
+#endif
 	const double y = __builtin_amdgcn_rsq(x);
 	double g = x * y, h = y * 0.5;
 	const double r = __builtin_fma(-h, g, 0.5);
 	g = __builtin_fma(g, r, g), h = __builtin_fma(h, r, h);
 	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
 	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+#if RMD_SQRT_RANGE_TEST == 1
+	return g;
+#else
 	return __builtin_amdgcn_class(x, 0x260) ? x : g; // +-0 and +inf return themselves (class mask: -0 | +0 | +inf)
+#endif
 }
 RMD_DEV double length(V3 a) { return sqrt64(dot(a, a)); }
 // a / b for a divisor whose correctly rounded reciprocal r = 1.0 / b was computed beforehand (host: exact_reciprocal(),
@@ -83,11 +106,19 @@ RMD_DEV double div_by(double a, double b, double r) {
 // sequence (v_rcp_f64 at 1/3 rate, two Newton steps, scaling and fix-up) would.  The one divisor that correction cannot
 // round is a root whose significand is all ones (Markstein): 1/root then lies 2^-106 above a rounding midpoint — and it is
 // common here, because re-normalising a unit vector takes the root of 1 - 2^-53.  In that case the quotient is the power
-// of two the estimate was rounded to plus one ulp, set directly.  Arguments outside [2^-700, 2^700] send the whole wave
+// of two the estimate was rounded to plus one ulp, set directly.  Arguments outside [2^-700, 2^700) send the whole wave
 // down the plain sqrt + division (one ballot).  tools/microbench/inv_length_check.hip compares the shortcut with
 // sqrt + division bit for bit: 0 mismatches in 3.4e11 arguments, 4.8e9 of them with all-ones roots.
 RMD_DEV void sqrt_and_inverse(double x, double &root, double &inv) {
+#ifndef RMD_SQRT_INV_RANGE_TEST
+#define RMD_SQRT_INV_RANGE_TEST 1 // an f64 compare costs as much as an f64 addition, an integer compare half (tools/microbench/valu_rate.hip): C2 51.3 -> 50.6 ms
+#endif
+#if RMD_SQRT_INV_RANGE_TEST
+	const uint32_t hi = (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32); // 2^-700 <= x < 2^700 as one unsigned range test on the high word
+	if (__ballot(hi - 0x14300000u >= 0x6BB00000u - 0x14300000u) != 0ull) {
+#else
 	if (__ballot(!(x >= 0x1p-700 && x <= 0x1p700)) != 0ull) {
+#endif
 		root = sqrt64(x);
 		inv = 1.0 / root;
 		return;
@@ -192,31 +223,42 @@ struct Rng {
 };
 
 // ---------------------------------------------------------------- primitives
+// The primitives come in two forms: `*_visit(..., on_hit)` calls on_hit(t) where the hit is found — what the closest-hit loops use, so that the
+// distance is consumed inside the branch that computed it and never has to exist, as a value, on the paths that miss (held in a variable that
+// leaves the branch it costs a 64-bit copy per nesting level and object: tools/experiments/README.md, round 5) — and the reference's
+// `intersects(ray) -> Option<distance>` shape built on top of it for everything else.
 // core/src/geometry/primitives/sphere.rs:11-27
-RMD_DEV bool sphere_intersect(V3 center, double radius, V3 ro, V3 rd, double &t_out) {
+template <class F>
+RMD_DEV void sphere_visit(V3 center, double radius, V3 ro, V3 rd, F &&on_hit) {
 	V3 c = center - ro;
 	double t = dot(c, rd);
 	V3 q = c - t * rd;
 	double p = dot(q, q);
 	double r2 = radius * radius;
-	if (p > r2) return false;
+	if (p > r2) return;
 	t -= sqrt64(r2 - p);
-	if (t <= 0.0) return false;
-	t_out = t;
-	return true;
+	if (t <= 0.0) return;
+	on_hit(t);
+}
+RMD_DEV bool sphere_intersect(V3 center, double radius, V3 ro, V3 rd, double &t_out) {
+	bool hit = false;
+	sphere_visit(center, radius, ro, rd, [&](double t) { t_out = t, hit = true; });
+	return hit;
 }
 // core/src/geometry/primitives/plane.rs:11-24
-RMD_DEV bool plane_intersect(V3 origin, V3 normal, V3 ro, V3 rd, double &t_out) {
+template <class F>
+RMD_DEV void plane_visit(V3 origin, V3 normal, V3 ro, V3 rd, F &&on_hit) {
 	double denom = dot(normal, -rd);
 	if (denom > 1e-6) {
 		V3 p0l0 = origin - ro;
 		double t = dot(p0l0, -normal) / denom;
-		if (t >= 0.0) {
-			t_out = t;
-			return true;
-		}
+		if (t >= 0.0) on_hit(t);
 	}
-	return false;
+}
+RMD_DEV bool plane_intersect(V3 origin, V3 normal, V3 ro, V3 rd, double &t_out) {
+	bool hit = false;
+	plane_visit(origin, normal, ro, rd, [&](double t) { t_out = t, hit = true; });
+	return hit;
 }
 // Two planes whose normals are exact negations of each other (the opposite walls of a box), tested together.  Plane::intersects
 // (plane.rs:11-24) is one-sided: a ray is tested further only against a plane it faces, `dot(normal, -rd) > 1e-6`.  With n_b = -n_a every
@@ -225,18 +267,55 @@ RMD_DEV bool plane_intersect(V3 origin, V3 normal, V3 ro, V3 rd, double &t_out) 
 // exclude each other, and a lane's one division is num / |denom_a| with ITS plane's numerator — the operands and the IEEE division
 // plane.rs:17 performs for that plane.  One division sequence at full lane occupancy instead of two at about half each.
 // `first` tells which plane a hit belongs to.
-RMD_DEV bool plane_pair_intersect(V3 origin_a, V3 normal_a, V3 origin_b, V3 normal_b, V3 ro, V3 rd, double &t_out, bool &first) {
+template <class F>
+RMD_DEV void plane_pair_visit(V3 origin_a, V3 normal_a, V3 origin_b, V3 normal_b, V3 ro, V3 rd, F &&on_hit) { // on_hit(t, first)
 	const double denom_a = dot(normal_a, -rd);
 	const bool faces_a = denom_a > 1e-6, faces_b = -denom_a > 1e-6; // = dot(normal_b, -rd) > 1e-6
 	const double num_a = dot(origin_a - ro, -normal_a), num_b = dot(origin_b - ro, -normal_b);
 	if (faces_a || faces_b) {
 		const double t = (faces_b ? num_b : num_a) / __builtin_fabs(denom_a);
-		if (t >= 0.0) {
-			t_out = t, first = faces_a;
-			return true;
-		}
+		if (t >= 0.0) on_hit(t, faces_a);
 	}
-	return false;
+}
+RMD_DEV bool plane_pair_intersect(V3 origin_a, V3 normal_a, V3 origin_b, V3 normal_b, V3 ro, V3 rd, double &t_out, bool &first) {
+	bool hit = false;
+	plane_pair_visit(origin_a, normal_a, origin_b, normal_b, ro, rd, [&](double t, bool f) { t_out = t, first = f, hit = true; });
+	return hit;
+}
+// The same three tests without control flow (RMD_FLAT_OBJECT_TESTS, the closest-hit loops): every lane computes the whole test and ONE condition
+// says whether its result counts.  The operations that produce a counted distance are those of the branching forms, in the same order, on the
+// same values; a lane whose ray misses computes a quotient or root nobody reads (a division by a small or zero denominator, the root of a negative
+// number: no traps on this hardware).  Why: a value that lives across a divergent branch and is assigned inside it — the closest distance and
+// object so far — costs the compiler a 64-bit and a 32-bit copy per nesting level (three or four levels per object), more than the tests' early
+// exits save (they only help when NO lane of the wave gets past them).
+RMD_DEV bool sphere_test_flat(V3 center, double radius, V3 ro, V3 rd, double &t_out) {
+	V3 c = center - ro;
+	double t = dot(c, rd);
+	V3 q = c - t * rd;
+	double p = dot(q, q);
+	double r2 = radius * radius;
+#if RMD_SQRT_RANGE_TEST == 1
+	t -= sqrt64(__builtin_fabs(r2 - p)); // (that form sends the wave down the compiler's sequence for a negative argument: a lane that misses takes the root of |r2 - p|, which nobody reads)
+#else
+	t -= sqrt64(r2 - p); // NaN where p > r2 (sqrt64's fast path takes negative arguments: only SMALL POSITIVE ones send the wave to the compiler's sequence)
+#endif
+	t_out = t;
+	return !(p > r2) && !(t <= 0.0);
+}
+RMD_DEV bool plane_test_flat(V3 origin, V3 normal, V3 ro, V3 rd, double &t_out) {
+	double denom = dot(normal, -rd);
+	V3 p0l0 = origin - ro;
+	double t = dot(p0l0, -normal) / denom;
+	t_out = t;
+	return denom > 1e-6 && t >= 0.0;
+}
+RMD_DEV bool plane_pair_test_flat(V3 origin_a, V3 normal_a, V3 origin_b, V3 normal_b, V3 ro, V3 rd, double &t_out, bool &first) {
+	const double denom_a = dot(normal_a, -rd);
+	const bool faces_a = denom_a > 1e-6, faces_b = -denom_a > 1e-6;
+	const double num_a = dot(origin_a - ro, -normal_a), num_b = dot(origin_b - ro, -normal_b);
+	const double t = (faces_b ? num_b : num_a) / __builtin_fabs(denom_a);
+	t_out = t, first = faces_a;
+	return (faces_a || faces_b) && t >= 0.0;
 }
 // core/src/geometry/primitives/aabb.rs:10-31 (fmin/fmax = Rust f64::min/max NaN rule)
 RMD_DEV bool aabb_intersect(V3 bmin, V3 bmax, V3 ro, V3 rd, double &tmin_out) {
@@ -273,6 +352,23 @@ RMD_DEV bool triangle_intersect(V3 v0, V3 edge1, V3 edge2, V3 ro, V3 rd, double 
 		return true;
 	}
 	return false;
+}
+// The same test without control flow (RMD_FLAT_TRIANGLE_TEST, the walk's chunk loop): a chunk tests 64 (ray, triangle) pairs of different rays and
+// cells, so an early exit is only taken when all 64 fail the same test — practically never — while the four nested branches cost their scalar
+// bookkeeping and a copy of `t` per level every time.  The conditions are the negations of the exits above, written so that a NaN takes the same
+// way through them (every compare with a NaN is false there and here).
+RMD_DEV bool triangle_test_flat(V3 v0, V3 edge1, V3 edge2, V3 ro, V3 rd, double &t_out) {
+	constexpr double EPSILON = 0.00000001;
+	V3 h = cross(rd, edge2);
+	double a = dot(edge1, h);
+	double f = 1.0 / a;
+	V3 s = ro - v0;
+	double u = f * dot(s, h);
+	V3 q = cross(s, edge1);
+	double v = f * dot(rd, q);
+	double t = f * dot(edge2, q);
+	t_out = t;
+	return !(a < EPSILON && a > -EPSILON) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && t > EPSILON;
 }
 // triangle.rs:47-68
 RMD_DEV double heron_area_of_sides(double ab, double ac, double bc) {

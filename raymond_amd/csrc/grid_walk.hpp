@@ -265,6 +265,9 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 // are fixed registers named in the clobber list (an asm statement takes at most 30 operands).  Every step uses up one of the
 // lane's exit counters, so a lane leaves the loop after at most res.x + res.y + res.z steps.  Arithmetic on t_max, the axis
 // choice, the index, the end-of-array test and the order of the recorded candidates are those of RMD_DDA_ITERATION, bit for bit.
+#ifndef RMD_FLAT_TRIANGLE_TEST
+#define RMD_FLAT_TRIANGLE_TEST 0 // device_core.hpp: triangle_test_flat — measured: seven more spilled registers, C3 426.5 vs 421.0 ms: not used
+#endif
 #ifndef RMD_WALK_ASM_LOOP
 #define RMD_WALK_ASM_LOOP 1
 #endif
@@ -414,7 +417,11 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 	int32_t dix = 0, diy = 0, diz = 0;
 	uint32_t idx = 0, remx = 1, remy = 1, remz = 1;
 	uint32_t prev = kNoCell; // the cell the ray stood on before `idx`: selects the triangle list of a candidate (device_types.hpp: cell_entries)
+#if RMD_WALK_STATE_STAND_IN
 	double tmx = 0.0, tmy = 0.0, tmz = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
+#else
+	double tmx, tmy, tmz, tdx, tdy, tdz; // set where a walk starts (or goes on) and only read by lanes that walk
+#endif
 #if RMD_DIAG
 	const bool skip_walk = (debug_flags & 2u) != 0u, skip_tests = (debug_flags & 1u) != 0u; // timing ablations: wrong results, DIAG builds only
 #else
@@ -634,8 +641,17 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				const uint32_t own_now = own_x;
 				if (base + 64u * ahead < total) search(base + 64u * ahead, own_x, tri_x);
-				double t = 0.0;
+#if RMD_FLAT_TRIANGLE_TEST
+				double t;
+				const bool h = triangle_test_flat(r.v0, r.e1, r.e2, pro, prd, t) && w < total;
+#else
+#if RMD_TRIANGLE_T_STAND_IN
+				double t = 0.0; // (A/B: round 4's form — a stand-in costs a 64-bit copy at each of the test's four exits)
+#else
+				double t; // set by a hit and only read — below, by readlane — for the lanes of `h`
+#endif
 				const bool h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t) && w < total;
+#endif
 #if !defined(RMD_STAMP_OUTER_ONLY)
 				RMD_STAMP(5)
 #endif

@@ -51,6 +51,9 @@ RMD_DEV void report_fault(const RenderParams &P, uint32_t code, uint32_t detail)
 #ifndef RMD_BOUND_TRIPS
 #define RMD_BOUND_TRIPS 1
 #endif
+#ifndef RMD_FLAT_OBJECT_TESTS
+#define RMD_FLAT_OBJECT_TESTS 1
+#endif
 #ifndef RMD_BOUND_DRAWS
 #define RMD_BOUND_DRAWS 1
 #endif
@@ -70,35 +73,63 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	double closest = kFMax;
 	int best = -1;
 	uint32_t sub = 0;
+#if RMD_FLAT_OBJECT_TESTS
+	if constexpr (!GRID) {
+		// without grid objects: tests without control flow, the running minimum updated by selects (device_core.hpp: *_test_flat)
+		for (uint32_t i = 0; i < n_objects; i++) {
+			const DevObject &o = objs[i];
+			double t;
+			bool ok;
+			int idx = (int)i;
+			if (o.geometry_kind == 0u) {
+				if (o.pair_info != 0u) {
+					if (o.pair_info & kPairTestedAtPartner) continue; // at its partner's turn
+					const uint32_t e = o.pair_info - 1u;
+					bool first;
+					ok = plane_pair_test_flat(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, t, first);
+					idx = first ? (int)e : (int)i;
+					ok = ok && want && lex_less(t, idx, closest, best);
+				} else {
+					ok = plane_test_flat(ld3(o.origin), ld3(o.normal), ro, rd, t) && want && t < closest;
+				}
+			} else {
+				ok = sphere_test_flat(ld3(o.origin), o.radius, ro, rd, t) && want && t < closest;
+			}
+			closest = ok ? t : closest, best = ok ? idx : best;
+		}
+		t_best = closest, sub_best = 0u;
+		return best;
+	}
+#endif
 	for (uint32_t i = 0; i < n_objects; i++) {
 		const DevObject &o = objs[i];
-		double t; // set by a hit and only read after one: no stand-in value (it cost a 64-bit move per object and nesting level)
-		uint32_t tri = 0;
-		bool hit = false;
+		// planes and spheres: the hit is consumed where it is found (device_core.hpp: *_visit)
 		if (o.geometry_kind == 0u) {
-			if (o.pair_info != 0u) { // a plane with an exactly opposite partner (device_core.hpp: plane_pair_intersect)
-				if (o.pair_info & kPairTestedAtPartner) continue; // at its partner's turn
-				const uint32_t e = o.pair_info - 1u;                 // the earlier partner, e < i
-				bool first = false;
-				if (want) hit = plane_pair_intersect(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, t, first);
+			if (o.pair_info != 0u) { // a plane with an exactly opposite partner (device_core.hpp: plane_pair_visit)
+				const uint32_t e = o.pair_info - 1u; // the earlier partner, e < i (a plane marked kPairTestedAtPartner is tested at its partner's turn)
 				// Scene::intersect's scan keeps the lexicographic minimum of (distance, index); objects between e and i have had their turn
-				if (want && hit && lex_less(t, first ? (int)e : (int)i, closest, best)) closest = t, best = first ? (int)e : (int)i, sub = 0u;
-				continue;
-			}
-			if (want) hit = plane_intersect(ld3(o.origin), ld3(o.normal), ro, rd, t);
+				if (want && (o.pair_info & kPairTestedAtPartner) == 0u)
+					plane_pair_visit(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, [&](double t, bool first) {
+						const int idx = first ? (int)e : (int)i;
+						if (lex_less(t, idx, closest, best)) closest = t, best = idx, sub = 0u;
+					});
+			} else if (want)
+				plane_visit(ld3(o.origin), ld3(o.normal), ro, rd, [&](double t) {
+					if (t < closest) closest = t, best = (int)i, sub = 0u;
+				});
 		} else if (o.geometry_kind == 1u) {
-			if (want) hit = sphere_intersect(ld3(o.origin), o.radius, ro, rd, t);
+			if (want)
+				sphere_visit(ld3(o.origin), o.radius, ro, rd, [&](double t) {
+					if (t < closest) closest = t, best = (int)i, sub = 0u;
+				});
 		} else if constexpr (GRID) {
 			const DevGrid &g = grids[o.grid_index];
 			const uint32_t *mask = (lds_masks && g.mask_lds_word != 0xFFFFFFFFu) ? lds_masks + g.mask_lds_word : nullptr;
+			double t;
+			uint32_t tri = 0;
+			bool hit = false;
 			grid_intersect_wave(g, mask, scr, want, ro, rd, hit, t, tri, debug_flags, dbg);
-		}
-		if (want && hit) {
-			if (t < closest) {
-				closest = t;
-				best = (int)i;
-				sub = tri;
-			}
+			if (want && hit && t < closest) closest = t, best = (int)i, sub = tri;
 		}
 	}
 	t_best = closest;

@@ -35,6 +35,18 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int n, uint32_t seed) {
 			if (OP == 20) d[i] = (double)(uint32_t)a[i] * 1.0000001, a[i] = (uint32_t)d[i]; // v_cvt_f64_u32 + mul + v_cvt_u32_f64
 			if (OP == 21) a[i] = (a[i] ^ 0x9E3779B9u ^ (uint32_t)it) + 1u;     // v_xor3 + add
 			if (OP == 22) d[i] = __builtin_fabs(d[i] - 1.5) < 0.25 ? 1.0 : d[i] * 1.0000001; // sub-free: cmp with modifiers + mul + 2 cndmask
+			// compares in isolation (round 5): one compare + one v_cndmask_b32 on an integer chain; the f64 operand does not change
+			if (OP == 23) asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(d[i]), "v"(d[(i + 1) % CHAINS]), "v"(a[(i + 1) % CHAINS]) : "vcc");
+			if (OP == 24) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(a[(i + 2) % CHAINS]), "v"(a[(i + 3) % CHAINS]), "v"(a[(i + 1) % CHAINS]) : "vcc");
+			if (OP == 25) asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(d[i]), "v"(d[(i + 1) % CHAINS]), "v"(a[(i + 1) % CHAINS]) : "vcc");
+			if (OP == 26) asm volatile("v_cmp_class_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(d[i]), "v"(a[(i + 2) % CHAINS]), "v"(a[(i + 1) % CHAINS]) : "vcc");
+			if (OP == 27) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(a[(i + 1) % CHAINS]) : "vcc"); // the select alone
+			if (OP == 28) asm volatile("v_max_f64 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) % CHAINS]));
+			if (OP == 29) asm volatile("v_cmp_lt_f64 s[20:21], %1, %2\n\tv_cndmask_b32 %0, %0, %3, s[20:21]" : "+v"(a[i]) : "v"(d[i]), "v"(d[(i + 1) % CHAINS]), "v"(a[(i + 1) % CHAINS]) : "s20", "s21");
+			if (OP == 30) asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cmp_lt_f64 s[20:21], %2, %1\n\ts_and_b64 vcc, vcc, s[20:21]\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(d[i]), "v"(d[(i + 1) % CHAINS]), "v"(a[(i + 1) % CHAINS]) : "vcc", "s20", "s21", "scc");
+			if (OP == 31) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(a[(i + 2) % CHAINS]), "v"(a[(i + 3) % CHAINS]), "v"(a[(i + 1) % CHAINS]) : "vcc");
+			if (OP == 32) asm volatile("v_mov_b64 %0, %1" : "=v"(d[i]) : "v"(d[(i + 1) % CHAINS]));
+			if (OP == 33) asm volatile("v_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc" : "+v"(a[i]), "+v"(a[(i + 4) % CHAINS]) : "v"(a[(i + 1) % CHAINS]), "v"(a[(i + 2) % CHAINS]) : "vcc");
 		}
 	}
 	uint32_t r = 0;
@@ -86,5 +98,16 @@ int main() {
 	run<20>("cvt_f64_u32 + mul_f64 + cvt_u32_f64", 3);
 	run<21>("v_xor3 + add", 2);
 	run<22>("add + cmp + mul + 2 cndmask", 5);
+	run<23>("v_cmp_lt_f64 (vcc) + cndmask", 2);
+	run<24>("v_cmp_lt_u32 (vcc) + cndmask", 2);
+	run<25>("v_cmp_lt_u64 (vcc) + cndmask", 2);
+	run<26>("v_cmp_class_f64 + cndmask", 2);
+	run<27>("v_cndmask_b32", 1);
+	run<28>("v_max_f64", 1);
+	run<29>("v_cmp_lt_f64 (sgpr) + cndmask", 2);
+	run<30>("2 v_cmp_lt_f64 + s_and + cndmask", 4);
+	run<31>("v_cmp_lt_f32 (vcc) + cndmask", 2);
+	run<32>("v_mov_b64", 1);
+	run<33>("2 v_cndmask_b32", 2);
 	return 0;
 }
