@@ -483,6 +483,7 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 		const std::vector<double> &aux = derived->aux;
 		for (int a = 0; a < 3; a++) {
 			d.bbox_min[a] = g.bbox_min[a], d.bbox_max[a] = g.bbox_max[a], d.cell_size[a] = g.cell_size[a];
+			d.inv_cell_size[a] = rmd::exact_reciprocal(g.cell_size[a]);
 			d.res[a] = g.resolution[a];
 		}
 		d.n_cells = g.n_cells, d.n_tris = g.n_tris;

@@ -45,6 +45,11 @@ RMD_DEV V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
 RMD_DEV V3 hadamard(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 RMD_DEV double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; } // cgmath: mul_element_wise().sum()
 RMD_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+#if RMD_NO_BRANCH_HINTS
+#define RMD_UNLIKELY(c) (c)
+#else
+#define RMD_UNLIKELY(c) __builtin_expect(!!(c), 0) // the fallback of a wave-level range test: laid out away from the path every trip takes
+#endif
 // IEEE square root.  The compiler's expansion of sqrt(double) pre-scales arguments below 2^-767 (compare, two selects, two ldexp around the
 // refinement) and ends with a select that returns +-0 and +inf unchanged (class compare, two selects); no length, discriminant or area on this
 // path is that small, zero or infinite in the ordinary course, so when every lane of the wave holds a finite argument >= 2^-767 — ONE unsigned
@@ -61,7 +66,7 @@ RMD_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * 
 RMD_DEV double sqrt64(double x) {
 #if RMD_SQRT_RANGE_TEST == 1
 	const uint32_t hi = (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32);
-	if (__ballot(hi - 0x10000000u >= 0x7FF00000u - 0x10000000u) != 0ull) return __builtin_sqrt(x);
+	if (RMD_UNLIKELY(__ballot(hi - 0x10000000u >= 0x7FF00000u - 0x10000000u) != 0ull)) return __builtin_sqrt(x);
 #elif RMD_SQRT_RANGE_TEST == 2
 	// +0 and positive arguments below 2^-767 as ONE unsigned compare of the high word (an f64 compare costs as much as an f64 addition, an integer
 	// one half: tools/microbench/valu_rate.hip); negative, infinite and NaN arguments take the refinement as before
@@ -115,7 +120,7 @@ RMD_DEV void sqrt_and_inverse(double x, double &root, double &inv) {
 #endif
 #if RMD_SQRT_INV_RANGE_TEST
 	const uint32_t hi = (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32); // 2^-700 <= x < 2^700 as one unsigned range test on the high word
-	if (__ballot(hi - 0x14300000u >= 0x6BB00000u - 0x14300000u) != 0ull) {
+	if (RMD_UNLIKELY(__ballot(hi - 0x14300000u >= 0x6BB00000u - 0x14300000u) != 0ull)) {
 #else
 	if (__ballot(!(x >= 0x1p-700 && x <= 0x1p700)) != 0ull) {
 #endif

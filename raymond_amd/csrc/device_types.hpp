@@ -54,6 +54,7 @@ struct alignas(16) DevGrid {
 	double bbox_min[3];
 	double bbox_max[3];
 	double cell_size[3];
+	double inv_cell_size[3]; // 1.0 / cell_size, correctly rounded, or NaN (internal.hpp: exact_reciprocal): the divisors of the walk's first-cell quotients (div_by)
 	uint64_t res[3];
 	uint64_t n_cells;
 	const CellEntry *cell_entries; // n_cells x kEntrySlots x {first id, count}

@@ -435,11 +435,24 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			int32_t cx = 0, cy = 0, cz = 0;
 			V3 cs = ld3(g.cell_size);
 			V3 start = ro - bmin;
-			bool ok = cast_i32(start.x / cs.x, cx) && cast_i32(start.y / cs.y, cy) && cast_i32(start.z / cs.z, cz);
+			// (position / cell_size).cast::<i32>() (:94, :98): the cell size is the grid's, so the quotient comes from its exact reciprocal where the host
+			// could provide one (device_core.hpp: div_by — three instructions for an IEEE division's fourteen; a non-finite position gives NaN
+			// where the division gives an infinity: the cast refuses both)
+			const V3 ics = ld3(g.inv_cell_size);
+#if RMD_NO_CELL_RECIPROCAL
+			const bool by_reciprocal = false; // (A/B)
+#else
+			const bool by_reciprocal = ics.x == ics.x && ics.y == ics.y && ics.z == ics.z; // uniform
+#endif
+			auto cell_of = [&](V3 p, int32_t &ix, int32_t &iy, int32_t &iz) {
+				if (RMD_UNLIKELY(!by_reciprocal)) return cast_i32(p.x / cs.x, ix) && cast_i32(p.y / cs.y, iy) && cast_i32(p.z / cs.z, iz);
+				return cast_i32(div_by(p.x, cs.x, ics.x), ix) && cast_i32(div_by(p.y, cs.y, ics.y), iy) && cast_i32(div_by(p.z, cs.z, ics.z), iz);
+			};
+			bool ok = cell_of(start, cx, cy, cz);
 			if (ok && (cx < 0 || cy < 0 || cz < 0)) {
 				V3 outer_pos = ro + rd * t_outer;
 				start = outer_pos - bmin;
-				ok = cast_i32(start.x / cs.x, cx) && cast_i32(start.y / cs.y, cy) && cast_i32(start.z / cs.z, cz);
+				ok = cell_of(start, cx, cy, cz);
 			}
 			ok = ok && !(rd.x != rd.x || rd.y != rd.y || rd.z != rd.z); // signum(NaN).cast::<i32>() panics: miss
 			if (ok) {

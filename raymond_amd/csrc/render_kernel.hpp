@@ -425,7 +425,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 					pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
 				} else {
 #if RMD_BOUND_DRAWS
-					if (drawn < floor) report_fault(Pt, kFaultWorkLoop, drawn); // (never reached; the poisoned counter ends the launch)
+					if (RMD_UNLIKELY(drawn < floor)) report_fault(Pt, kFaultWorkLoop, drawn); // (never reached; the poisoned counter ends the launch)
 #endif
 					wt = drawn / Pt.split_k;
 					const uint32_t part = drawn - wt * Pt.split_k;
@@ -442,7 +442,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		// and pair it holds and leaves through the loop's own exit below.)
 		trips_since_walk += 0x100u;
 		const bool stalled = trips_since_walk >= stall_bound; // (never true: see trips_since_walk)
-		if (stalled) {
+		if (RMD_UNLIKELY(stalled)) {
 			report_fault(Pt, kFaultTripLoop, first);
 			complete = false, lens_failed = false, cut = false, has_ray = false, to_shade = false, need_sample = false, alive = false;
 			if constexpr (CHAIN) pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
@@ -778,7 +778,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		// state in which a trip runs with no lane —
 		// unlike a pool with THREE lists, where all three can be short of a full trip while the empty list holds nothing
 		// (tools/experiments/README.md: the run that was killed for silence in round 4).
-		if (trips_left-- == 0ull) { // (never reached: see above) — the wave reports, drops what it holds and leaves through the loop's own exit
+		if (RMD_UNLIKELY(trips_left-- == 0ull)) { // (never reached: see above) — the wave reports, drops what it holds and leaves through the loop's own exit
 			report_fault(Pt, kFaultSortedTripLoop, work_item);
 			n_hit = 0u, next_item = pool_items;
 		}
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ?
 			if (item >= n_items) break;
 #if RMD_BOUND_DRAWS
 			floor = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor);
-			if (item < floor) { // (never reached)
+			if (RMD_UNLIKELY(item < floor)) { // (never reached)
 				report_fault(P, kFaultWorkLoop, item);
 				break;
 			}
