@@ -454,7 +454,8 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		// trip is (C) classification -> (B) hand-out and next rays -> (A) intersection; a surface classified here is shaded a few lines
 		// further down, with nothing but the hand-out in between (the mesh kernel: two spilled registers instead of four).
 		bool terminal = lens_failed || cut;
-		V3 L = mk(0.0, 0.0, 0.0);
+		bool emitted = false; // the path has reached a light (:250-252): its radiance is fetched below, outside the nest of branches (a value that is
+		                      // assigned three branches deep costs a copy per level and component on every trip)
 		if (complete) {
 			if (LIST && path_obj) {
 				size_t pi = (size_t)list_idx * (RMD_PATH_STRIDE) + path_len;
@@ -468,7 +469,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 				const DevObject &o = lobjs[oi];
 				const V3 frag = ro + rd * t; // :246
 				if (o.material_kind == 2u) {
-					L = ld3(o.color); // :250-252 Emission
+					emitted = true; // :250-252 Emission
 					terminal = true;
 				} else {
 					V3 normal;
@@ -507,6 +508,8 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			has_ray = false;
 		}
 		if (terminal) {
+			V3 L = mk(0.0, 0.0, 0.0); // :242 miss, bounce limit, a black path ended: radiance 0 (times the throughput: a non-finite throughput makes NaN of it, as in the reference)
+			if (emitted) L = ld3(lobjs[oi].color);
 			L = hadamard(load_T(), L);
 			if constexpr (to_buffer) {
 				// one aligned 32-byte sector per sample (kSampleStride doubles): lanes finish their samples on different trips, so a
@@ -814,12 +817,18 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 			const V3 frag = mk(stack.frag[0][e], stack.frag[1][e], stack.frag[2][e]);
 			const uint32_t x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 			rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (item >> 6);
+#if RMD_SORT_PREDICATED_ARMS
 			if (active) {
+#else
+			{ // every lane shades — a lane beyond the trip's n the stack's entry 0, a hit of this work item like any other; what it computes is never
+			  // stored (`active` gates everything below).  Shading under `if (active)` made ro, rd and T values that are assigned inside a divergent
+			  // branch: nine 64-bit copies of the other lanes' undefined values per trip.
+#endif
 				shade(Pt, normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, ro, rd, T);
 				depth++;
 				// (see render_wave: a path whose throughput is exactly zero is ended unless the caller traces such paths on)
 				const bool black = Pt.end_black_paths != 0u && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
-				failed = depth > Pt.bounce_limit || black;
+				failed = active && (depth > Pt.bounce_limit || black);
 			}
 		} else {
 			// ---------------- GI: the work item's next 64 (pixel, sample) pairs, one per lane (slots outside a ragged tile are skipped)
@@ -830,11 +839,15 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 			const uint32_t x = tile.x0 + (item & 7u), y = tile.y0 + ((item >> 3) & 7u);
 			rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (item >> 6);
 			T = mk(1.0, 1.0, 1.0);
+#if RMD_SORT_PREDICATED_ARMS
 			if (active) {
+#else
+			{ // (likewise: a lane without a pair computes the ray of a pixel position outside the tile, which nobody reads)
+#endif
 				double u0, u1;
 				rng.next2(Pt.key0, Pt.key1, u0, u1); // block 0: the pixel jitter (:326-327)
 				primary_ray(Pt, x, y, u0, u1, ro, rd);
-				if (Pt.use_dof) failed = !thin_lens_from_pinhole(Pt, ro, rd, rng, ro, rd); // the reference panics there; the sample contributes zero
+				if (Pt.use_dof) failed = active && !thin_lens_from_pinhole(Pt, ro, rd, rng, ro, rd); // the reference panics there; the sample contributes zero
 			}
 		}
 		// ---------------- src/trace.rs:239 — closest hit of every lane that has a ray
@@ -847,8 +860,8 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		const int oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, nullptr, *no_scratch, want, ro, rd, t, sub, 0u, nullptr);
 		if constexpr (kSortObjPrio != 0) __builtin_amdgcn_s_setprio(0);
 		// ---------------- classification (the rules of render_wave's phase C)
-		bool terminal = failed, park = false;
-		V3 L = mk(0.0, 0.0, 0.0), frag, normal;
+		bool terminal = failed, park = false, emitted = false;
+		V3 frag, normal;
 		RMD_UNDEF3(frag) RMD_UNDEF3(normal)
 		if (want) {
 			if (oi < 0) {
@@ -857,7 +870,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 				const DevObject &o = lobjs[oi];
 				frag = ro + rd * t; // :246
 				if (o.material_kind == 2u) {
-					L = ld3(o.color); // :250-252 Emission
+					emitted = true; // :250-252 Emission
 					terminal = true;
 				} else {
 					if (o.geometry_kind == 0u) normal = ld3(o.normal);       // plane.rs:28-32
@@ -871,6 +884,8 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 			}
 		}
 		if (active && terminal) { // the finished sample: T (.) L into its 32-byte sector of the per-sample buffer
+			V3 L = mk(0.0, 0.0, 0.0);
+			if (emitted) L = ld3(lobjs[oi].color); // (fetched here, outside the nest of branches that found the light)
 			L = hadamard(T, L);
 			RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (((size_t)wt * Pt.sample_count + pool_first + (item >> 6)) * 64u + (item & 63u)) * kSampleStride;
 			store_sample(dst, L);
