@@ -265,6 +265,9 @@ RMD_DEV void dda_collect_candidates(const uint32_t *lds_mask, uint32_t mask_shif
 // are fixed registers named in the clobber list (an asm statement takes at most 30 operands).  Every step uses up one of the
 // lane's exit counters, so a lane leaves the loop after at most res.x + res.y + res.z steps.  Arithmetic on t_max, the axis
 // choice, the index, the end-of-array test and the order of the recorded candidates are those of RMD_DDA_ITERATION, bit for bit.
+#ifndef RMD_SPHERE_PREFILTER
+#define RMD_SPHERE_PREFILTER 1 // grid_intersect_wave: the triangle tests of a round behind a bounding-sphere pre-test
+#endif
 #ifndef RMD_FLAT_TRIANGLE_TEST
 #define RMD_FLAT_TRIANGLE_TEST 0 // device_core.hpp: triangle_test_flat — measured: seven more spilled registers, C3 426.5 vs 421.0 ms: not used
 #endif
@@ -487,12 +490,17 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 		}
 		*carried = false;
 	}
-	auto put_aside = [&]() {
-		carry->tm[0][lane] = tmx, carry->tm[1][lane] = tmy, carry->tm[2][lane] = tmz;
-		carry->idx[lane] = idx, carry->prev[lane] = prev;
-		carry->rem[0][lane] = remx, carry->rem[1][lane] = remy, carry->rem[2][lane] = remz;
-		*carried = true;
-		walking = false;
+	// A lane whose walk is put aside stops walking — the stepping runs under `walking`, so its DDA state stays in its registers as it is — and the
+	// state is stored when the call ends (store_aside, below): during the call the carry's LDS serves the rounds' pre-test (the ring of pairs).
+	bool aside = false;
+	auto put_aside = [&]() { aside = true, walking = false; };
+	auto store_aside = [&]() {
+		if (aside) {
+			carry->tm[0][lane] = tmx, carry->tm[1][lane] = tmy, carry->tm[2][lane] = tmz;
+			carry->idx[lane] = idx, carry->prev[lane] = prev;
+			carry->rem[0][lane] = remx, carry->rem[1][lane] = remy, carry->rem[2][lane] = remz;
+			*carried = true;
+		}
 	};
 
 	bool found = false;
@@ -686,9 +694,94 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 					}
 				}
 			};
+			// One chunk of tests behind the sphere pre-test (RMD_SPHERE_PREFILTER; the walks of the split launches, DEEP).  85 % of the (ray, triangle)
+			// pairs a round numbers fail a test that costs a quarter of triangle.rs:11-44: the ray's line passes the triangle's sphere (DevGrid::tri_sph,
+			// 32 bytes instead of the 72-byte record) by.  pretest() runs that on a chunk — owner search, ray fetch and index lookahead as in chunk() —
+			// and appends the pairs that pass, in their order, to a ring in LDS (the wave's WalkCarry: its contents are loaded when a call begins and
+			// stored when it ends; in between it is free); whenever 64 pairs wait — and for what is left at the round's end — full() runs the
+			// reference's test on them and applies the hits exactly as chunk() does.  The pairs that pass keep their ascending (lane, candidate,
+			// triangle) order, so the hit rule sees the same hits in the same order; a pair that is dropped is a pair whose test fails
+			// (api.cpp: triangle_sphere has the argument; tests/test_gpu_faults.py counts, in a DIAG build, that no dropped pair passes the test).
+			[[maybe_unused]] unsigned long long *ring = reinterpret_cast<unsigned long long *>(carry); // 128 entries of {owner | slot << 8, triangle}
+			[[maybe_unused]] uint32_t ring_head = 0u, ring_tail = 0u;
+			[[maybe_unused]] const RMD_GLOBAL double *spheres = as_global(g.tri_sph);
+			[[maybe_unused]] const double sph_kb = g.sph_kb;
+			[[maybe_unused]] auto full = [&]() {
+				const uint32_t n = umin(ring_tail - ring_head, 64u);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const unsigned long long e = ring[(ring_head + lane) & 127u]; // (a lane beyond n reads an older entry or what the carry left there: masked on the next lines)
+				ring_head += n;
+				const bool valid = lane < n;
+				if (count_events && lane == 0) atomicAdd(&dbg[18], 1ull);
+				const uint32_t own_now = valid ? (uint32_t)e : 0u, tri = valid ? (uint32_t)(e >> 32) : 0u;
+				const TriRecord r = load_record(recs + (size_t)tri * kTriRecStride);
+				const int src = (int)((own_now & 63u) << 2);
+				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
+				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
+				double t; // set by a hit and only read — below, by readlane — for the lanes of `h`
+				const bool h = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, t) && valid;
+				unsigned long long hits = __ballot(h);
+				while (hits) {
+					const int l = (int)__builtin_ctzll(hits);
+					hits &= hits - 1ull;
+					const uint32_t ol = readlane_u32(own_now, l);
+					const double tl = readlane_f64(t, l);
+					const uint32_t tril = readlane_u32(tri, l);
+					const uint32_t slot = ol >> 8;
+					if (lane == (ol & 63u) && (!any || slot == any_slot)) {
+						if (tl < closest) { // `closest` is still 5712515.0 until the first accepted hit
+							closest = tl;
+							closest_tri = tril;
+							any_slot = slot;
+							any = true;
+						}
+					}
+				}
+				__builtin_amdgcn_wave_barrier(); // every lane has read its entry before the ring is written again
+			};
+			[[maybe_unused]] auto pretest = [&](uint32_t base, uint32_t &own_x, uint32_t &tri_x) {
+				const uint32_t w = base + lane;
+				const uint32_t tri = tri_x, own_now = own_x;
+				const RMD_GLOBAL double *sp = spheres + (size_t)tri * 4u;
+				const V3 c = ld3(sp);
+				const double r2a = sp[3];
+				const int src = (int)((own_x & 63u) << 2);
+				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
+				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
+				if (base + 64u * ahead < total) search(base + 64u * ahead, own_x, tri_x);
+				const V3 d = c - pro;
+				const double along = dot(d, prd), dd = dot(d, d);
+				const bool pass = w < total && dd - along * along <= r2a + sph_kb * dd; // (a NaN anywhere: dropped — the reference's test fails on a NaN too)
+#if RMD_DIAG
+				if (count_events && (debug_flags & 64u)) { // cross-check: a pair the pre-test drops must fail the reference's test (dbg[16] stays 0)
+					const TriRecord r = load_record(recs + (size_t)tri * kTriRecStride);
+					double tt;
+					const bool hh = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, tt) && w < total;
+					const unsigned long long bad = __ballot(hh && !pass);
+					if (bad != 0ull && lane == 0) atomicAdd(&dbg[16], (unsigned long long)__popcll(bad));
+				}
+#endif
+				const unsigned long long pm = __ballot(pass);
+				if (pass) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))) & 127u] = (unsigned long long)own_now | ((unsigned long long)tri << 32);
+				ring_tail += (uint32_t)__popcll(pm);
+				if (count_events && lane == 0) atomicAdd(&dbg[17], (unsigned long long)__popcll(pm));
+				if (ring_tail - ring_head >= 64u) full();
+			};
 			uint32_t own_a = 0, tri_a = 0;
 			search(0u, own_a, tri_a);
-			if constexpr (ahead == 2u) { // two register pairs take turns (no copies: a copy would wait for the load it copies)
+			if constexpr (DEEP && RMD_SPHERE_PREFILTER) {
+				static_assert(sizeof(WalkCarry) >= 128u * sizeof(unsigned long long), "the ring of pairs that passed the pre-test lives in the wave's WalkCarry");
+				uint32_t own_b = 0, tri_b = 0;
+				if (64u < total) search(64u, own_b, tri_b);
+				for (uint32_t base = 0; base < total; base += 128u) {
+					pretest(base, own_a, tri_a);
+					if (base + 64u >= total) break;
+					pretest(base + 64u, own_b, tri_b);
+				}
+				if (ring_tail != ring_head) full(); // (fewer than 64 are left: full() is run as soon as 64 wait)
+			} else if constexpr (ahead == 2u) { // two register pairs take turns (no copies: a copy would wait for the load it copies)
 				uint32_t own_b = 0, tri_b = 0;
 				if (64u < total) search(64u, own_b, tri_b);
 				for (uint32_t base = 0; base < total; base += 128u) {
@@ -715,6 +808,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			break;
 		}
 	}
+	if constexpr (DEEP) store_aside();
 	RMD_STAMP(7)
 #if RMD_DIAG
 	if (stamp && lane == 0) {

@@ -6,7 +6,9 @@ failure mode there is a hang: `TaskHandle::await` polls a counter that a panicke
 The bounds cannot be reached with the product library, so this test loads the DIAG build of the same sources (`make -C raymond_amd/csrc diag`:
 diag/libraymond_hip.so, built by __graft_entry__.build()) whose RMD_DEBUG bits FORCE each bound: 32 = the trip loops' (stall watch of
 render_wave, trip count of render_wave_sorted), 128 = a persistent wave's work loop.  (A grid walk's round and stepping loops carry no counter of
-their own: they are bounded by the rays' exit counters — grid_walk.hpp says why.)  One child process, run once."""
+their own: they are bounded by the rays' exit counters — grid_walk.hpp says why.)  One child process, run once.
+
+The same DIAG build also checks the walk's sphere pre-test (bit 64): see the second test."""
 import os
 import subprocess
 import sys
@@ -86,6 +88,67 @@ def test_every_render_loop_reports_a_forced_bound_as_a_device_fault(product_lib)
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     sys.stdout.write(r.stdout)
     assert r.returncode == 0 and "faults ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+PRETEST_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from raymond_amd import lib, render, scenes
+from raymond_amd.scene import Settings, generate_tiles
+
+assert lib.LIB_PATH.endswith("diag/libraymond_hip.so"), lib.LIB_PATH
+os.environ["RMD_DEBUG"] = "72"  # 8: event counters, 64: every pair the sphere pre-test drops is ALSO run through the reference's test and counted if it passes
+
+def run(name, scene, W, H, spp, end_black_paths=False, dof=False):
+    with render.Context(0) as ctx:
+        cam = scenes.camera(W, H, aperture_radius=0.05 if dof else 0.0)
+        st = Settings(cam, sample_count=spp, bounce_limit=5, seed=scenes.SEED)
+        st.end_black_paths, st.use_dof = end_black_paths, dof
+        ds, fb = render.DeviceScene(ctx, scene), render.Framebuffer(ctx, W, H)
+        sys.stderr.write("== %%s\n" %% name), sys.stderr.flush()
+        render.render_tiles(ctx, ds, cam, st, generate_tiles(W, H, st.tile_size), fb)
+        info = ctx.last_launch_info()
+        assert info.buffered == 1 and info.has_grid == 1, name  # the split launch: the walk with the pre-test
+        fb.close(), ds.close()
+
+run("benchmark mesh", scenes.gold_dragon_standin(), 384, 256, 16)
+run("benchmark mesh, black paths ended, thin lens", scenes.gold_dragon_standin(), 256, 256, 16, True, True)
+# the same shape in triangles a hundred times smaller and eight times larger (coarse meshes: few, large triangles seen at grazing angles too)
+run("fine mesh", scenes.mesh_scene(scenes.lumpy_sphere_mesh(n=160, extent=(0.23, 0.17, 0.1), centre=(0.0, -0.5, 0.0))), 256, 256, 16)
+run("coarse mesh", scenes.mesh_scene(scenes.lumpy_sphere_mesh(n=4)), 256, 256, 32)
+run("coarse flat mesh", scenes.mesh_scene(scenes.lumpy_sphere_mesh(n=8, extent=(3.0, 0.5, 0.3))), 256, 256, 32)
+print("pretest ok")
+"""
+
+
+def test_the_sphere_pre_test_drops_no_pair_that_passes_the_reference_test(product_lib):
+    """grid_walk.hpp: a (ray, triangle) pair whose line passes the triangle's sphere by is not run through triangle.rs:11-44.  In the DIAG build
+    (RMD_DEBUG bit 64) every dropped pair IS run through it as well and counted if it passes: the count stays 0, and the pre-test does drop pairs."""
+    import re
+
+    assert os.path.exists(DIAG_LIB), "build the DIAG library: python -c 'import __graft_entry__ as g; g.build()'"
+    env = dict(os.environ, RAYMOND_HIP_LIB=DIAG_LIB)
+    env.pop("RMD_DEBUG", None)
+    r = subprocess.run([sys.executable, "-c", PRETEST_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "pretest ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    scenes_seen, name = {}, None
+    for line in r.stderr.splitlines():
+        if line.startswith("== "):
+            name = line[3:]
+        m = re.search(r"tests=(\d+)", line)
+        if m and name:
+            scenes_seen.setdefault(name, {})["tests"] = scenes_seen.get(name, {}).get("tests", 0) + int(m.group(1))
+        m = re.search(r"pairs passed=(\d+) full chunks=(\d+) .*must be 0\)=(\d+)", line)
+        if m and name:
+            d = scenes_seen.setdefault(name, {})
+            d["passed"] = d.get("passed", 0) + int(m.group(1))
+            d["wrongly_dropped"] = d.get("wrongly_dropped", 0) + int(m.group(3))
+    print(scenes_seen)
+    assert len(scenes_seen) == 5, r.stderr[-3000:]
+    for name, d in scenes_seen.items():
+        assert d["wrongly_dropped"] == 0, (name, d)
+        assert 0 < d["passed"] < d["tests"], (name, d)  # it ran, and it dropped pairs
 
 
 def test_the_product_build_ignores_the_diag_switches(gpu_ctx):
