@@ -415,7 +415,7 @@ def main():
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
         # <MODE, GRID> as rocprofv3 prints it: launches split every tile's samples over several waves (MODE 1) + the ordered sum
         # mesh scenes: persistent render kernel + sum_kernel; spheres: the render kernel's waves add the samples themselves
-        kname = ("rmd::render_kernel<1, true, true> + rmd::sum_kernel" if scenes.CONFIGS[name][0] != "reflective_spheres"
+        kname = ("rmd::render_kernel<1, true, true, true> + rmd::sum_kernel" if scenes.CONFIGS[name][0] != "reflective_spheres"
                  else "rmd::render_kernel<1, false, true> (persistent workgroups, ordered sample sum inside)")
         out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"],
                          "nonfinite_pixels": main_run["nonfinite_pixels"]}
@@ -479,14 +479,14 @@ def main():
         rl.update({
             "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch; rmd_settings.flags 0 = "
                         "reference-identical: every path traced to its end" % rspp,
-            "kernel": "rmd::render_kernel<1, true, true> + rmd::sum_kernel",
+            "kernel": "rmd::render_kernel<1, true, true, true> + rmd::sum_kernel",
             "definition": "achieved / frac = ALGORITHMIC bytes per launch / launch time — most of these bytes are answered by LDS (occupancy mask), L2 and the "
                           "Infinity Cache, so the figure saturates and does not rank kernels any more; measured_gbs / measured_frac = L2<->fabric bytes by PMC, "
                           "an upper bound on HBM bytes; valu_issue_frac = 1.667 ns / (ns per wave-level vector instruction per SIMD): the bound that binds; "
                           "useful_frac = valu_issue_frac x lane utilisation",
             "how": "achieved = algorithmic bytes per launch (8 B x visited cells that hold a triangle + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
                    "oracle counters in tests/golden/work_counters.json: C3_reference for flags 0, C3 for ending_black_paths, + 24 B/pixel) / mean launch duration "
-                   "from HIP events on the launch stream; profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true> (persistent workgroups) + "
+                   "from HIP events on the launch stream; profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true, true> (persistent workgroups, chained work items) + "
                    "sum_kernel over the same launches; valu / traffic: committed rocprofv3 --pmc passes (separate SQ / FETCH_SIZE / WRITE_SIZE passes), "
                    "\"stale\": true when the sources have changed since",
         })

@@ -230,7 +230,7 @@ enum {
 	RMD_TUNE_SPLIT_MIN_SAMPLES = 6, /* RMD_SPLIT_MIN_SAMPLES: fewest samples per pixel a work item of a split launch may hold (0 = the library's
 	                              choice: 4 in scenes with grids — two items per wave tile from 4 samples per pixel on — 64 without)      */
 	RMD_TUNE_CHAIN_ITEMS = 7,  /* RMD_CHAIN_ITEMS: split launches of scenes with grids whose persistent waves draw their next work item while the last
-	                              paths of the current one finish: 0 = the library's choice (launches of at most 96 samples per pixel), 1 = never,
+	                              paths of the current one finish: 0 = the library's choice (every such launch), 1 = never,                     
 	                              2 = always                                                                                                  */
 	RMD_TUNE_COUNT = 8
 };

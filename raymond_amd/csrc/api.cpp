@@ -682,7 +682,7 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 		// ordered sum, so its items are larger — about 24 per wave slot, at least 64 samples each (round 4, full C2 frame: 52.9 ms at 3 .. 6
 		// items per wave tile, 55.2 at 9, 59.1 at 12; an N-way tile share, tools/shard_split.py: N = 8 7.4 ms at 7 .. 10, 8.5 at 16, 9.2 at 3;
 		// N = 2 27.3 at 6 .. 7, 29.0 at 2, 29.8 at 12)
-		const uint32_t waves_per_slot = has_grid ? 64u : 24u;
+		const uint32_t waves_per_slot = has_grid ? 256u : 24u; // (grid scenes: 64 until the work items were chained — an item's end costs a chaining wave nothing, and smaller items even the launch's tail out: C3 382.8 ms at 9 items per wave tile, 381.3 at 32, 381.0 at 64)
 		k = (waves_per_slot * ctx->wave_slots + n_wave_tiles - 1u) / n_wave_tiles;
 		if (has_grid && k < 2u) k = 2u; // the mesh kernel's direct instantiation is the slower one at any size
 		// (launches short enough for the instantiation whose waves chain their work items — an item's end costs them nothing — take items of 2)
@@ -774,7 +774,7 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		Q.sample_count = settings->sample_count - done < per_pass ? (uint32_t)(settings->sample_count - done) : per_pass;
 		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
 		Q.buffered = buffered ? 1u : 0u;
-		{ // short launches chain their work items (launch.hpp: kChainMaxSamples; RMD_TUNE_CHAIN_ITEMS: 1 = never, 2 = always)
+		{ // split launches of grid scenes chain their work items (launch.hpp: kChainMaxSamples; RMD_TUNE_CHAIN_ITEMS: 1 = never, 2 = always)
 			const int64_t force = ctx->tunable[RMD_TUNE_CHAIN_ITEMS];
 			Q.chain_items = (buffered && scene->n_grids != 0u && (force == 2 || (force == 0 && Q.sample_count <= rmd::kChainMaxSamples))) ? 1u : 0u;
 		}

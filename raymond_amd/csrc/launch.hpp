@@ -53,9 +53,11 @@ constexpr uint32_t kSplitMinSamplesGrid = RMD_SPLIT_MIN_SAMPLES_GRID;
 #define RMD_SORTED_MIN_SAMPLES 128
 #endif
 constexpr uint32_t kSortedMinSamples = RMD_SORTED_MIN_SAMPLES;
-// split launches of scenes with grids of at most this many samples per pixel run the instantiation whose waves chain their work items
+// split launches of scenes with grids of at most this many samples per pixel run the instantiation whose waves chain their work items: all of
+// them since the round's second half (the chained instantiation used to spill 27 registers against 15 and lost 2.6 % at 500 samples per pixel —
+// hence a limit of 96 —; at 11 against 9 it wins at every size: C3 at 128 / 200 / 500 spp 101.7 / 157.2 / 387.8 -> 98.9 / 154.1 / 384.5 ms)
 #ifndef RMD_CHAIN_MAX_SAMPLES
-#define RMD_CHAIN_MAX_SAMPLES 96
+#define RMD_CHAIN_MAX_SAMPLES 0x7FFFFFFF
 #endif
 constexpr uint32_t kChainMaxSamples = RMD_CHAIN_MAX_SAMPLES;
 // walks put aside (grid_walk.hpp: cut_lanes): a walk call leaves its last K walkers to the wave's next call
