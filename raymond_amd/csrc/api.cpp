@@ -213,6 +213,7 @@ RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const r
 	// material of roughness 0 or a sphere of radius 0 make non-finite radiance reachable without a mesh; such a scene is traced like one with a grid)
 	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : ((st->flags & RMD_RENDER_END_BLACK_PATHS) || !scene || (scene->n_grids == 0u && scene->regular)) ? 1u : 0u;
 	P.shade_last_depth = (scene && !scene->regular) ? 1u : 0u;
+	P.axis_pairs = scene ? scene->axis_pairs : 0u;
 	P.fault = ctx ? ctx->d_fault : nullptr;
 	P.walk_batch = rmd::kWalkBatchDefault;
 	if (ctx && ctx->tunable[RMD_TUNE_WALK_BATCH] > 0) P.walk_batch = (uint32_t)ctx->tunable[RMD_TUNE_WALK_BATCH]; // any value gives the same image
@@ -483,9 +484,30 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 			break;
 		}
 	}
+	// ... and a pair whose normals are exactly +e_k and -e_k — the walls of an axis-aligned room — is tested with one component of the ray instead of
+	// three dot products (scene_split.hpp: axis_pairs_visit has the argument for "same bits"): one pair per axis, in scenes of regular parameters
+	uint32_t axis_pairs = 0;
+#ifndef RMD_AXIS_PAIRS
+#define RMD_AXIS_PAIRS 1
+#endif
+	for (uint32_t j = 0; j < n_objects && j < 1023u && regular && RMD_AXIS_PAIRS; j++) {
+		if (hobj[j].geometry_kind != RMD_GEOM_PLANE || hobj[j].pair_info == 0u || (hobj[j].pair_info & rmd::kPairTestedAtPartner)) continue;
+		const uint32_t i = hobj[j].pair_info - 1u;
+		int k = -1, nonzero = 0;
+		for (int a = 0; a < 3; a++)
+			if (hobj[i].normal[a] != 0.0) nonzero++, k = a;
+		if (nonzero != 1 || (hobj[i].normal[k] != 1.0 && hobj[i].normal[k] != -1.0) || ((axis_pairs >> (10 * k)) & 1023u) != 0u) continue;
+		axis_pairs |= (j + 1u) << (10 * k);
+		hobj[j].flags |= rmd::kObjAxisPair | ((uint32_t)k << rmd::kObjAxisShift) | (hobj[i].normal[k] == 1.0 ? rmd::kObjAxisEarlierIsPlus : 0u);
+		hobj[i].flags |= rmd::kObjAxisPair;
+		hobj[j].partner_origin_k = hobj[i].origin[k];
+		hobj[j].pair_info = rmd::kPairTestedAtPartner | rmd::kPairAxis | i; // the object loops pass both planes by ("tested at its partner's turn"):
+		hobj[i].pair_info |= rmd::kPairAxis;                                 // their turn is axis_pairs_visit's, ahead of the loop
+	}
 	sc = new (std::nothrow) rmd_scene();
 	if (!sc) return rmd::fail(ctx, RMD_ERR_OUT_OF_MEMORY, "rmd_scene_create: allocation failed");
 	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids, sc->regular = regular;
+	sc->axis_pairs = axis_pairs;
 	for (uint32_t i = 0; i < n_objects; i++) sc->n_grid_objects += objects[i].geometry_kind == RMD_GEOM_GRID ? 1u : 0u;
 	auto upload = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
 		*dst = nullptr;

@@ -22,11 +22,16 @@ struct alignas(16) DevObject {
 	double metalness; // 0.0 Diffuse, 1.0 Metal (src/trace.rs:248-249)
 	uint32_t flags;   // kObj*
 	uint32_t _pad2;
-	double _pad1;
+	double partner_origin_k; // kObjAxisPair, on the later plane of the pair: origin[k] of its partner
 };
 constexpr uint32_t kObjBlackDiffuse = 1u; // Diffuse with colour (0, 0, 0): its diffuse bounce has weight exactly zero (src/trace.rs:279-281)
+// A pair of opposite planes whose normals are exactly +e_k and -e_k (the walls of an axis-aligned room), in a scene of regular parameters: tested
+// by axis_pairs_visit (scene_split.hpp) ahead of the object loop, which skips both planes.  Set on the LATER plane of the pair (the one whose
+// pair_info names its partner): kObjAxisPair | k << 8 | (the EARLIER plane is the one with normal +e_k) << 10.
+constexpr uint32_t kObjAxisPair = 2u, kObjAxisShift = 8u, kObjAxisEarlierIsPlus = 1u << 10;
 static_assert(sizeof(DevObject) == 128, "DevObject layout");
 constexpr uint32_t kPairTestedAtPartner = 0x80000000u;
+constexpr uint32_t kPairAxis = 0x40000000u; // with kPairTestedAtPartner, on BOTH planes of an axis pair (kObjAxisPair): pair_info & 0x3FFFFFFF = the partner's index
 
 // One AccGrid (reference core/src/geometry/acc_grid.rs:27-33), re-laid out at upload for the wave-cooperative walk
 // (grid_walk.hpp).  `cells[c] -> mapping_table[off] = count, idx...` (acc_grid.rs:67-74) becomes
@@ -116,6 +121,8 @@ struct RenderParams {
 	                                    // finish (render_kernel.hpp: render_wave, CHAIN) — launches of few samples per pixel, where an item's drain is a fifth of it
 	uint32_t _pad1;
 	uint32_t buffered;                  // 1: the tiles-buffered instantiation (pooled (pixel, sample) hand-out, per-sample scratch, ordered sum) — also with split_k = 1
+	uint32_t axis_pairs;                // three 10-bit fields, one per axis k: index + 1 of the later plane of THE pair of opposite planes with normals +-e_k that is
+	uint32_t _pad2;                     //   tested ahead of the object loop (kObjAxisPair), 0 = none
 	uint32_t *fault;                    // the context's fault words (host memory mapped into the device's address space; kFault*): a wave whose loop runs past
 	                                    // its bound reports here, poisons work_counter so that the launch drains, and leaves (render_kernel.hpp: report_fault)
 };

@@ -115,6 +115,6 @@ hipError_t launch_tonemap(hipStream_t stream, const double *accum, uint8_t *rgb8
 hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in, int in_stride, double *out, int out_stride,
                         const RenderParams &P);
 hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,
-                              const DevGrid *grids, uint32_t n_grids, uint32_t mask_words_total, const double *rays, double *out);
+                              const DevGrid *grids, uint32_t n_grids, uint32_t mask_words_total, uint32_t axis_pairs, const double *rays, double *out);
 
 } // namespace rmd

@@ -206,7 +206,7 @@ static rmd_status scene_probe(rmd_context *ctx, const rmd_scene *scene, int mode
 	RMD_HIP(ctx, hipMalloc(&dout.p, n * 3 * sizeof(double)));
 	RMD_HIP(ctx, hipMemcpyAsync(din.p, ray6, n * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	RMD_HIP(ctx, rmd::launch_probe_scene(ctx->stream, mode, g, (uint32_t)n, scene->d_objects, scene->n_objects, scene->d_grids,
-	                                     scene->n_grids, scene->mask_words_total, (const double *)din.p, (double *)dout.p));
+	                                     scene->n_grids, scene->mask_words_total, scene->axis_pairs, (const double *)din.p, (double *)dout.p));
 	std::vector<double> out(n * 3);
 	RMD_HIP(ctx, hipMemcpyAsync(out.data(), dout.p, out.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));

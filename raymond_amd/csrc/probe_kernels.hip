@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const dou
 // 64-thread workgroups; the grids' occupancy masks are read from LDS exactly as in the render kernel when `use_masks`.
 __global__ __launch_bounds__(64) void probe_scene_kernel(int mode, uint32_t g, uint32_t n, const DevObject *__restrict__ objs,
                                                          uint32_t n_objects, const DevGrid *__restrict__ grids, uint32_t n_grids,
-                                                         uint32_t mask_words_total, const double *__restrict__ rays,
+                                                         uint32_t mask_words_total, uint32_t axis_pairs, const double *__restrict__ rays,
                                                          double *__restrict__ out) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	uint32_t *lmasks = reinterpret_cast<uint32_t *>(smem);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void probe_scene_kernel(int mode, uint32_t g, u
 	if (mode == 0) {
 		double t;
 		uint32_t sub;
-		int oi = scene_intersect_wave<true>(objs, n_objects, grids, lds_masks, scr, want, ro, rd, t, sub);
+		int oi = scene_intersect_wave<true>(objs, n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, axis_pairs, 0u, nullptr, true); // (a test's rays: any bit pattern)
 		o0 = oi, o1 = oi >= 0 ? t : 0.0, o2 = oi >= 0 ? sub : 0u;
 	} else {
 		double t = 0.0;
@@ -150,7 +150,7 @@ hipError_t launch_probe(hipStream_t stream, int op, uint32_t n, const double *in
 }
 
 hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t n, const DevObject *objs, uint32_t n_objects,
-                              const DevGrid *grids, uint32_t n_grids, uint32_t mask_words_total, const double *rays, double *out) {
+                              const DevGrid *grids, uint32_t n_grids, uint32_t mask_words_total, uint32_t axis_pairs, const double *rays, double *out) {
 	if (n == 0) return hipSuccess;
 	const size_t probe_lds = (size_t)((mask_words_total + 3u) & ~3u) * 4u + sizeof(WalkScratch);
 	if (probe_lds > 64u * 1024u) {
@@ -158,7 +158,7 @@ hipError_t launch_probe_scene(hipStream_t stream, int mode, uint32_t g, uint32_t
 		if (e != hipSuccess) return e;
 	}
 	hipLaunchKernelGGL(probe_scene_kernel, dim3((n + 63u) / 64u), dim3(64), probe_lds, stream, mode, g, n, objs,
-	                   n_objects, grids, n_grids, mask_words_total, rays, out);
+	                   n_objects, grids, n_grids, mask_words_total, axis_pairs, rays, out);
 	return hipGetLastError();
 }
 

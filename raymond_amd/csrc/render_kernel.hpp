@@ -69,10 +69,11 @@ constexpr uint32_t kStallBound = 1u << 18; // render_wave: trips a wave may take
 template <bool GRID>
 RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids,
                                  const uint32_t *lds_masks, WalkScratch &scr, bool want, V3 ro, V3 rd, double &t_best, uint32_t &sub_best,
-                                 uint32_t debug_flags = 0, unsigned long long *dbg = nullptr) {
+                                 uint32_t axis_pairs, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr, bool arbitrary_rays = false) {
 	double closest = kFMax;
 	int best = -1;
 	uint32_t sub = 0;
+	axis_pairs_visit(objs, axis_pairs, want, ro, rd, closest, best, arbitrary_rays); // (the room's walls: scene_split.hpp; `sub` stays 0 for a plane)
 #if RMD_FLAT_OBJECT_TESTS
 	if constexpr (!GRID) {
 		// without grid objects: tests without control flow, the running minimum updated by selects (device_core.hpp: *_test_flat)
@@ -90,10 +91,10 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 					idx = first ? (int)e : (int)i;
 					ok = ok && want && lex_less(t, idx, closest, best);
 				} else {
-					ok = plane_test_flat(ld3(o.origin), ld3(o.normal), ro, rd, t) && want && t < closest;
+					ok = plane_test_flat(ld3(o.origin), ld3(o.normal), ro, rd, t) && want && lex_less(t, idx, closest, best);
 				}
 			} else {
-				ok = sphere_test_flat(ld3(o.origin), o.radius, ro, rd, t) && want && t < closest;
+				ok = sphere_test_flat(ld3(o.origin), o.radius, ro, rd, t) && want && lex_less(t, idx, closest, best);
 			}
 			closest = ok ? t : closest, best = ok ? idx : best;
 		}
@@ -115,12 +116,12 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 					});
 			} else if (want)
 				plane_visit(ld3(o.origin), ld3(o.normal), ro, rd, [&](double t) {
-					if (t < closest) closest = t, best = (int)i, sub = 0u;
+					if (lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = 0u;
 				});
 		} else if (o.geometry_kind == 1u) {
 			if (want)
 				sphere_visit(ld3(o.origin), o.radius, ro, rd, [&](double t) {
-					if (t < closest) closest = t, best = (int)i, sub = 0u;
+					if (lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = 0u;
 				});
 		} else if constexpr (GRID) {
 			const DevGrid &g = grids[o.grid_index];
@@ -129,7 +130,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 			uint32_t tri = 0;
 			bool hit = false;
 			grid_intersect_wave(g, mask, scr, want, ro, rd, hit, t, tri, debug_flags, dbg);
-			if (want && hit && t < closest) closest = t, best = (int)i, sub = tri;
+			if (want && hit && lex_less(t, (int)i, closest, best)) closest = t, best = (int)i, sub = tri;
 		}
 	}
 	t_best = closest;
@@ -642,7 +643,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		const bool want = has_ray && !lens_failed;
 		if constexpr (GRID) {
 			if (want && new_ray) {
-				waiting = intersect_simple(objs, Pt.n_objects, grids, true, ro, rd, part_t, part_obj);
+				waiting = intersect_simple(objs, Pt.n_objects, grids, true, ro, rd, part_t, part_obj, Pt.axis_pairs);
 				part_sub = 0u, new_ray = false;
 			}
 			RMD_TSTAMP(tt_simple)
@@ -668,7 +669,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			complete = want && !waiting;
 			t = part_t, oi = part_obj, sub = part_sub;
 		} else {
-			oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, Pt.debug_flags, Pt.debug_counters);
+			oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, Pt.axis_pairs, Pt.debug_flags, Pt.debug_counters);
 			complete = want;
 		}
 	}
@@ -857,7 +858,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		// (the object loop is a chain of scalar loads with a few vector instructions behind each: at a raised priority it is through sooner and the SIMD's
 		// other waves fill what it leaves with their shading — RMD_SORT_OBJ_PRIO, measured −1.7 %)
 		if constexpr (kSortObjPrio != 0) __builtin_amdgcn_s_setprio(kSortObjPrio);
-		const int oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, nullptr, *no_scratch, want, ro, rd, t, sub, 0u, nullptr);
+		const int oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, nullptr, *no_scratch, want, ro, rd, t, sub, Pt.axis_pairs, 0u, nullptr);
 		if constexpr (kSortObjPrio != 0) __builtin_amdgcn_s_setprio(0);
 		// ---------------- classification (the rules of render_wave's phase C)
 		bool terminal = failed, park = false, emitted = false;

@@ -12,14 +12,58 @@ namespace rmd {
 // walks of the grid objects for the lanes that do, and merges.  Splitting the scan lets a lane WAIT for its walk until
 // enough other lanes of the wave need one too (RenderParams::walk_batch): a walk phase costs about the same for 15 rays as for 45,
 // because the wave steps until its longest walk ends either way.
-RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return t < t_best || (t == t_best && obj < obj_best); }
+RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return (t < t_best) | ((t == t_best) & (obj < obj_best)); } // (no short circuit: three compares and two scalar mask operations, no branch)
+// The walls of an axis-aligned room: up to three pairs of opposite planes with normals exactly +e_k / -e_k (RenderParams::axis_pairs, made by
+// rmd_scene_create in scenes of regular parameters), tested ahead of the object loops — which pass these planes by — with ONE component of the ray
+// where plane.rs:11-24 takes three dot products (19 f64 operations fewer per pair).  Same bits, because:
+//   * the scene is regular and a ray's origin and direction are therefore finite in every component, or NaN in every component (a degenerate
+//     mesh normal); with n = +-e_k the dot products (n.x*v.x + n.y*v.y) + n.z*v.z have two terms that are +-0 and one that is +-v_k, and
+//     x + (+-0) = x for every x that is not itself a zero — a NaN stays a NaN either way;
+//   * a ZERO denominator may come out with the other sign, which no comparison sees (`denom > 1e-6`), and a zero NUMERATOR (a ray that starts on the
+//     plane's coordinate) too, which the quotient's sign would show: one ballot sends the wave down the general test for that pair (never, in practice);
+//   * the plane with normal +e_k faces rays with -rd_k > 1e-6 and its numerator dot(o - ro, -n) is -(o_k - ro_k); the other one faces rd_k > 1e-6
+//     with numerator o_k - ro_k; the facing conditions exclude each other and the division is numerator / |rd_k| — plane_pair_test_flat's operands.
+// Hits are merged with the lexicographic rule (distance, object index), so the order in which the planes are visited does not matter
+// (core/src/scene.rs:54-74 keeps the first object of the closest distance).
+template <int K>
+RMD_DEV void axis_pair_test(const DevObject *__restrict__ objs, uint32_t j, bool want, V3 ro, V3 rd, double &closest, int &best, bool arbitrary_rays) {
+	const DevObject &o = objs[j];
+	const uint32_t e = o.pair_info & 0x3FFFFFFFu; // the earlier plane of the pair
+	const bool e_plus = (o.flags & kObjAxisEarlierIsPlus) != 0u;
+	const double o_e = o.partner_origin_k, o_j = o.origin[K]; // (the partner's coordinate sits in this object's record: one round of scalar loads, not two)
+	const double o_plus = e_plus ? o_e : o_j, o_minus = e_plus ? o_j : o_e; // the planes with normal +e_k / -e_k (uniform)
+	const int idx_plus = e_plus ? (int)e : (int)j, idx_minus = e_plus ? (int)j : (int)e;
+	const double rk = K == 0 ? rd.x : K == 1 ? rd.y : rd.z, pk = K == 0 ? ro.x : K == 1 ? ro.y : ro.z;
+	const bool faces_plus = -rk > 1e-6, faces_minus = rk > 1e-6;
+	const double num = faces_minus ? o_minus - pk : -(o_plus - pk);
+	// (arbitrary_rays: the probes' Scene::intersect on rays given by a test, which may be non-finite in SOME components: always the general test)
+	if (RMD_UNLIKELY(arbitrary_rays || __builtin_amdgcn_ballot_w64(num == 0.0) != 0ull)) { // the sign of a zero numerator is the full dot product's (any lane's: one that carries no ray may send the wave there for nothing)
+		double t;
+		bool first;
+		const bool hit = plane_pair_test_flat(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, t, first);
+		const int idx = first ? (int)e : (int)j;
+		const bool ok = hit && want && lex_less(t, idx, closest, best);
+		closest = ok ? t : closest, best = ok ? idx : best;
+		return;
+	}
+	const double t = num / __builtin_fabs(rk);
+	const int idx = faces_plus ? idx_plus : idx_minus;
+	const bool ok = (faces_plus || faces_minus) && t >= 0.0 && want && lex_less(t, idx, closest, best);
+	closest = ok ? t : closest, best = ok ? idx : best;
+}
+RMD_DEV void axis_pairs_visit(const DevObject *__restrict__ objs, uint32_t axis_pairs, bool want, V3 ro, V3 rd, double &closest, int &best, bool arbitrary_rays = false) {
+	if (axis_pairs & 1023u) axis_pair_test<0>(objs, (axis_pairs & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
+	if ((axis_pairs >> 10) & 1023u) axis_pair_test<1>(objs, ((axis_pairs >> 10) & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
+	if ((axis_pairs >> 20) & 1023u) axis_pair_test<2>(objs, ((axis_pairs >> 20) & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
+}
 #ifndef RMD_FLAT_OBJECT_TESTS
 #define RMD_FLAT_OBJECT_TESTS 1
 #endif
 RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, bool want, V3 ro, V3 rd,
-                              double &closest, int &best) {
+                              double &closest, int &best, uint32_t axis_pairs) {
 	closest = scalar_const(kFMax), best = -1;
 	bool enters = false;
+	axis_pairs_visit(objs, axis_pairs, want, ro, rd, closest, best);
 #if RMD_FLAT_OBJECT_TESTS
 	// tests without control flow, the running minimum updated by selects (device_core.hpp: *_test_flat)
 	for (uint32_t i = 0; i < n_objects; i++) {
@@ -36,10 +80,10 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 				idx = first ? (int)e : (int)i;
 				ok = ok && want && lex_less(t, idx, closest, best);
 			} else {
-				ok = plane_test_flat(ld3(o.origin), ld3(o.normal), ro, rd, t) && want && t < closest; // index order + strict '<' = the lexicographic minimum so far
+				ok = plane_test_flat(ld3(o.origin), ld3(o.normal), ro, rd, t) && want && lex_less(t, idx, closest, best); // (the axis pairs have had their turn ahead of the loop: the rule that does not depend on the order)
 			}
 		} else if (o.geometry_kind == 1u) {
-			ok = sphere_test_flat(ld3(o.origin), o.radius, ro, rd, t) && want && t < closest;
+			ok = sphere_test_flat(ld3(o.origin), o.radius, ro, rd, t) && want && lex_less(t, idx, closest, best);
 		} else {
 			const DevGrid &g = grids[o.grid_index];
 			double t_outer;
@@ -64,9 +108,9 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 				continue;
 			}
 			// index order + strict '<' = the lexicographic minimum so far
-			if (want) plane_visit(ld3(o.origin), ld3(o.normal), ro, rd, [&](double t) { if (t < closest) closest = t, best = (int)i; });
+			if (want) plane_visit(ld3(o.origin), ld3(o.normal), ro, rd, [&](double t) { if (lex_less(t, (int)i, closest, best)) closest = t, best = (int)i; });
 		} else if (o.geometry_kind == 1u) {
-			if (want) sphere_visit(ld3(o.origin), o.radius, ro, rd, [&](double t) { if (t < closest) closest = t, best = (int)i; });
+			if (want) sphere_visit(ld3(o.origin), o.radius, ro, rd, [&](double t) { if (lex_less(t, (int)i, closest, best)) closest = t, best = (int)i; });
 		} else {
 			const DevGrid &g = grids[o.grid_index];
 			double t_outer;
