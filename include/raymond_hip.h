@@ -232,7 +232,10 @@ enum {
 	RMD_TUNE_CHAIN_ITEMS = 7,  /* RMD_CHAIN_ITEMS: split launches of scenes with grids whose persistent waves draw their next work item while the last
 	                              paths of the current one finish: 0 = the library's choice (every such launch), 1 = never,                     
 	                              2 = always                                                                                                  */
-	RMD_TUNE_COUNT = 8
+	RMD_TUNE_AXIS_PAIRS = 8,   /* RMD_AXIS_PAIRS: read by rmd_scene_create — pairs of opposite planes whose normals are exactly +e_k / -e_k (the walls of an
+	                              axis-aligned room) tested with one component of the ray: 0 = the library's choice (yes, in scenes of regular
+	                              parameters), 1 = never (every pair takes the general test: same samples, bit for bit)                      */
+	RMD_TUNE_COUNT = 9
 };
 /* Free and total memory of the context's device, bytes (hipMemGetInfo): what a host that shares the GPU sizes its launches by. */
 rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, uint64_t *out_total_bytes);

@@ -70,6 +70,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_WALK_CUT] = env_int("RMD_WALK_CUT");
 		ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] = env_int("RMD_SPLIT_MIN_SAMPLES");
 		ctx->tunable[RMD_TUNE_CHAIN_ITEMS] = env_int("RMD_CHAIN_ITEMS");
+		ctx->tunable[RMD_TUNE_AXIS_PAIRS] = env_int("RMD_AXIS_PAIRS");
 		const char *form = std::getenv("RMD_LAUNCH_FORM");
 		ctx->tunable[RMD_TUNE_LAUNCH_FORM] = !form ? 0 : (std::strcmp(form, "per-item") == 0 || std::strcmp(form, "1") == 0) ? 1 : (std::strcmp(form, "persistent") == 0 || std::strcmp(form, "2") == 0) ? 2 : 0;
 #if RMD_DIAG
@@ -490,7 +491,7 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 #ifndef RMD_AXIS_PAIRS
 #define RMD_AXIS_PAIRS 1
 #endif
-	for (uint32_t j = 0; j < n_objects && j < 1023u && regular && RMD_AXIS_PAIRS; j++) {
+	for (uint32_t j = 0; j < n_objects && j < 1023u && regular && RMD_AXIS_PAIRS && ctx->tunable[RMD_TUNE_AXIS_PAIRS] != 1; j++) {
 		if (hobj[j].geometry_kind != RMD_GEOM_PLANE || hobj[j].pair_info == 0u || (hobj[j].pair_info & rmd::kPairTestedAtPartner)) continue;
 		const uint32_t i = hobj[j].pair_info - 1u;
 		int k = -1, nonzero = 0;

@@ -129,8 +129,8 @@ def test_header_constants_match_the_python_mirror():
 #include <stdio.h>
 #include "raymond_hip.h"
 int main(void) {
-  printf("%u %u %u %u %u %u %u %u %u %u %u %u %u\n", RMD_ABI_VERSION, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS, RMD_RENDER_END_BLACK_PATHS, (unsigned)RMD_TUNE_SAMPLE_SPLIT, (unsigned)RMD_TUNE_WALK_BATCH,
-         (unsigned)RMD_TUNE_MASK_BUDGET, (unsigned)RMD_TUNE_LAUNCH_FORM, (unsigned)RMD_TUNE_SCRATCH_CAP_MB, (unsigned)RMD_TUNE_WALK_CUT, (unsigned)RMD_TUNE_SPLIT_MIN_SAMPLES, (unsigned)RMD_TUNE_CHAIN_ITEMS, (unsigned)RMD_TUNE_COUNT);
+  printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u\n", RMD_ABI_VERSION, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS, RMD_RENDER_END_BLACK_PATHS, (unsigned)RMD_TUNE_SAMPLE_SPLIT, (unsigned)RMD_TUNE_WALK_BATCH,
+         (unsigned)RMD_TUNE_MASK_BUDGET, (unsigned)RMD_TUNE_LAUNCH_FORM, (unsigned)RMD_TUNE_SCRATCH_CAP_MB, (unsigned)RMD_TUNE_WALK_CUT, (unsigned)RMD_TUNE_SPLIT_MIN_SAMPLES, (unsigned)RMD_TUNE_CHAIN_ITEMS, (unsigned)RMD_TUNE_AXIS_PAIRS, (unsigned)RMD_TUNE_COUNT);
   return 0; }
 """
     with tempfile.TemporaryDirectory() as d:
@@ -139,7 +139,7 @@ int main(void) {
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [abi.RMD_ABI_VERSION, abi.RMD_RENDER_DOF, abi.RMD_RENDER_TRACE_BLACK_PATHS, abi.RMD_RENDER_END_BLACK_PATHS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_WALK_BATCH,
-                   abi.RMD_TUNE_MASK_BUDGET, abi.RMD_TUNE_LAUNCH_FORM, abi.RMD_TUNE_SCRATCH_CAP_MB, abi.RMD_TUNE_WALK_CUT, abi.RMD_TUNE_SPLIT_MIN_SAMPLES, abi.RMD_TUNE_CHAIN_ITEMS, 8]
+                   abi.RMD_TUNE_MASK_BUDGET, abi.RMD_TUNE_LAUNCH_FORM, abi.RMD_TUNE_SCRATCH_CAP_MB, abi.RMD_TUNE_WALK_CUT, abi.RMD_TUNE_SPLIT_MIN_SAMPLES, abi.RMD_TUNE_CHAIN_ITEMS, abi.RMD_TUNE_AXIS_PAIRS, 9]
     cam = scenes.camera(64, 48, aperture_radius=0.5)
     assert Settings(cam, 4).pod().flags == 0
     assert Settings(cam, 4, use_dof=True).pod().flags == abi.RMD_RENDER_DOF
