@@ -752,8 +752,9 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				if (base + 64u * ahead < total) search(base + 64u * ahead, own_x, tri_x);
 				const V3 d = c - pro;
-				const double along = dot(d, prd), dd = dot(d, d);
-				const bool pass = w < total && dd - along * along <= r2a + sph_kb * dd; // (a NaN anywhere: dropped — the reference's test fails on a NaN too)
+				// (the pre-test is not the reference's arithmetic: fused multiply-adds — fewer instructions, smaller errors than the allowance assumes)
+				const double along = __builtin_fma(d.x, prd.x, __builtin_fma(d.y, prd.y, d.z * prd.z)), dd = __builtin_fma(d.x, d.x, __builtin_fma(d.y, d.y, d.z * d.z));
+				const bool pass = w < total && __builtin_fma(-along, along, dd) <= __builtin_fma(sph_kb, dd, r2a); // (a NaN anywhere: dropped — the reference's test fails on a NaN too)
 #if RMD_DIAG
 				if (count_events && (debug_flags & 64u)) { // cross-check: a pair the pre-test drops must fail the reference's test (dbg[16] stays 0)
 					const TriRecord r = load_record(recs + (size_t)tri * kTriRecStride);
