@@ -150,8 +150,20 @@ RMD_DEV V3 normalize(V3 a) { // cgmath normalize_to(1.0): a * (1.0 / magnitude)
 RMD_DEV double dist(V3 a, V3 b) { return length(b - a); }     // MetricSpace::distance
 // a / |a| to within a few ulp: the hardware reciprocal square root and two Newton steps (16 instructions for normalize()'s 27).
 // For vectors that only enter a sample's weight (the half vector of the BRDF terms).
+// A dot product for quantities that only scale a sample's weight (RMD_WEIGHT_FMA: fused, three instructions for five; the reference's
+// unfused sum otherwise)
+#ifndef RMD_WEIGHT_FMA
+#define RMD_WEIGHT_FMA 0
+#endif
+RMD_DEV double dot_w(V3 a, V3 b) {
+#if RMD_WEIGHT_FMA
+	return __builtin_fma(a.x, b.x, __builtin_fma(a.y, b.y, a.z * b.z));
+#else
+	return dot(a, b);
+#endif
+}
 RMD_DEV V3 normalize_for_weight(V3 a) {
-	const double x = dot(a, a), h = 0.5 * x;
+	const double x = dot_w(a, a), h = 0.5 * x;
 	double y = __builtin_amdgcn_rsq(x);
 	y = y * __builtin_fma(-(h * y), y, 1.5);
 	y = y * __builtin_fma(-(h * y), y, 1.5);
@@ -646,7 +658,7 @@ RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const 
 	// ---- SHADE, second half: the bounce's weight (:275-282 / :301-318) and the bounce ray's origin (:269 / :300)
 	if (do_shade) {
 		const V3 normal = in.normal;
-		const double n_dot_sw = dot(normal, sw);
+		const double n_dot_sw = dot_w(normal, sw);
 		// Weight of the bounce.  trace() returns  diffuse (:281-282)  ((A (.) radiance) * cos) / (prob_d * pdf)
 		//                                         specular (:315-318) (((A (.) radiance) * cos) / (1 - prob_d)) / pdf
 		// i.e. radiance times a per-channel weight known before the recursive call; the kernel multiplies the weights forward
@@ -661,7 +673,7 @@ RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const 
 		// :276 halfway of (sample_world, view); :307-308 normalise sample_world once more first — it is a unit vector already, the
 		// second normalisation moves it by at most an ulp, and only this weight would see that
 		const V3 halfway = normalize_for_weight(sw + view);
-		const double h_dot_v = dot(halfway, view);
+		const double h_dot_v = dot_w(halfway, view);
 		const double fc = diffuse ? fmax(h_dot_v, 0.0) : h_dot_v; // :277 clamps, :309 does not
 		const V3 F = f0 + (mk(1.0, 1.0, 1.0) - f0) * pow5(1.0 - fc); // fresnel_schlick :384-386
 		V3 vec;
@@ -673,13 +685,14 @@ RMD_DEV void next_ray(const RenderParams &P, bool do_shade, bool do_prim, const 
 			Dn = prob_d * pdf_d;     // :282
 		} else {
 			const double a2 = in.roughness * in.roughness; // Q4
-			const double ndh = dot(normal, halfway);
+			const double ndh = dot_w(normal, halfway);
 			const double den = (ndh * ndh) * (a2 - 1.0) + 1.0;
 			const double Dd = fmax(kPi * den * den, 1e-7); // :367-368
 			const double k = (in.roughness * in.roughness) / 8.0; // :374
-			const double g1n = fmax(dot(normal, view), 0.0), g2n = fmax(n_dot_sw, 0.0); // :373
+			const double n_dot_v = dot_w(normal, view);
+			const double g1n = fmax(n_dot_v, 0.0), g2n = fmax(n_dot_sw, 0.0); // :373
 			const double g1d = g1n * (1.0 - k) + k, g2d = g2n * (1.0 - k) + k;         // :375-377
-			const double denominator = 4.0 * dot(normal, view) * n_dot_sw + 0.001;     // :312
+			const double denominator = 4.0 * n_dot_v * n_dot_sw + 0.001;     // :312
 			const double hv4 = 4.0 * h_dot_v;
 			vec = F;
 			N = (((a2 * g1n) * g2n) * n_dot_sw) * hv4; // cos_theta = n.l unclamped (:306)
