@@ -134,7 +134,7 @@ static_assert(kWalkSearchAhead == 1u || kWalkSearchAhead == 2u, "the search runs
 struct alignas(16) WalkScratch {
 	uint32_t start[64 * kWalkCand]; // by key: number of the pair's first test in the round (exclusive prefix sum of the counts); during the stepping,
 	                                // the cell BEFORE candidate m of lane l at [m * 64 + l]
-	uint32_t first[64 * kWalkCand]; // by key: first entry of the pair's list in tri_ids; during the stepping, candidate m of lane l at [m * 64 + l]
+	uint32_t first[64 * kWalkCand]; // by key: first entry of the pair's list in tri_ids minus the number of the pair's first test; during the stepping, candidate m of lane l at [m * 64 + l]
 	uint32_t marker[64];            // per 64-test chunk: lane + 1 of the lane whose tests begin at that position
 };
 
@@ -617,7 +617,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				uint32_t run = my_begin;
 #pragma unroll
 				for (uint32_t m = 0; m < kWalkCand; m++) {
-					scr.start[lane * kWalkCand + m] = run, scr.first[lane * kWalkCand + m] = c_first[m];
+					scr.start[lane * kWalkCand + m] = run, scr.first[lane * kWalkCand + m] = c_first[m] - run; // (first entry of the pair's list MINUS the number of its first test: test w reads entry w + that)
 					run += c_count[m];
 				}
 			}
@@ -636,14 +636,13 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				own = 0;
 				uint32_t id_index = 0;
 				if (w < total) {
-					uint32_t slot = 0, slot_start = scr.start[owner_lane * kWalkCand];
+					// the pair's slot: the LAST one whose tests begin at or before w — the starts do not decrease from slot to slot (an empty slot shares its
+					// start with the next one), so that is the number of slots 1 .. 3 whose start is <= w
+					uint32_t slot = 0;
 #pragma unroll
-					for (uint32_t m = 1; m < kWalkCand; m++) {
-						const uint32_t sm = scr.start[owner_lane * kWalkCand + m];
-						if (sm <= w) slot = m, slot_start = sm; // an empty slot shares its start with the next one: the last match is the non-empty pair
-					}
+					for (uint32_t m = 1; m < kWalkCand; m++) slot += scr.start[owner_lane * kWalkCand + m] <= w ? 1u : 0u;
 					own = owner_lane | (slot << 8);
-					id_index = scr.first[owner_lane * kWalkCand + slot] + (w - slot_start);
+					id_index = scr.first[owner_lane * kWalkCand + slot] + w;
 				}
 				tri_id = ids[id_index]; // (a lane without a test reads entry 0) — on its way while the current chunk is tested
 				__builtin_amdgcn_wave_barrier(); // every lane has read the markers before the next search rewrites them
