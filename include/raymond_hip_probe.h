@@ -64,6 +64,12 @@ rmd_status rmd_probe_trace_samples(rmd_context *ctx, const rmd_scene *scene, con
                                    size_t n, const uint32_t *xy2, const uint32_t *sample, double *rgb_out, int32_t *path_obj,
                                    uint32_t *path_sub);
 
+/* Host only (no device needed): the sphere rmd_scene_create puts around a triangle for the grid walk's pre-test — out5 = centre (3), inflated
+ * squared radius r2a, the triangle's distance-proportional allowance kb (a grid uses the largest of its triangles').  A (ray, triangle) pair whose
+ * line passes the centre at more than sqrt(r2a + kb * |centre - origin|^2) is not run through triangle.rs:11-44; tests/test_pretest_allowance.py
+ * checks, with the reference's test evaluated in binary64 on adversarial pairs, that no such pair would have passed it. */
+rmd_status rmd_probe_triangle_sphere(size_t n, const double *pos9, double *out5);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,7 +68,7 @@ struct alignas(16) DevGrid {
 	const double *tri_pos;      // n_tris * 9: v0 v1 v2 (Heron normal, triangle.rs:47-68)
 	const double *tri_nrm;      // n_tris * 9: n0 n1 n2
 	const double *tri_aux;      // n_tris * 4: |v0v1|, |v0v2|, Heron area of the triangle, its exact reciprocal or NaN (internal.hpp: triangle_aux)
-	const double *tri_sph;      // n_tris * 4: centre and inflated squared radius r2a of a sphere around the triangle (api.cpp: triangle_sphere): the
+	const double *tri_sph;      // n_tris * 4: centre and inflated squared radius r2a of a sphere around the triangle (internal.hpp: triangle_sphere): the
 	double sph_kb;              //   walk's pre-test drops a pair whose line passes the centre at more than sqrt(r2a + sph_kb * |centre - origin|^2)
 	const uint32_t *mask_words; // occupancy bitmask (global copy, staged into LDS by every workgroup)
 	uint64_t n_tris;

@@ -700,7 +700,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 			// stored when it ends; in between it is free); whenever 64 pairs wait — and for what is left at the round's end — full() runs the
 			// reference's test on them and applies the hits exactly as chunk() does.  The pairs that pass keep their ascending (lane, candidate,
 			// triangle) order, so the hit rule sees the same hits in the same order; a pair that is dropped is a pair whose test fails
-			// (api.cpp: triangle_sphere has the argument; tests/test_gpu_faults.py counts, in a DIAG build, that no dropped pair passes the test).
+			// (internal.hpp: triangle_sphere has the argument; tests/test_pretest_allowance.py checks it on adversarial pairs; tests/test_gpu_faults.py counts, in a DIAG build, that no dropped pair passes the test).
 			[[maybe_unused]] unsigned long long *ring = reinterpret_cast<unsigned long long *>(carry); // 128 entries of {owner | slot << 8, triangle}
 			[[maybe_unused]] uint32_t ring_head = 0u, ring_tail = 0u;
 			[[maybe_unused]] const RMD_GLOBAL double *spheres = as_global(g.tri_sph);

@@ -3,6 +3,8 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <limits>
+#include <algorithm>
 #include <cstring>
 
 #include <memory>
@@ -101,6 +103,50 @@ inline double exact_reciprocal(double b) {
 	const double m = std::fabs(b);
 	if (!(m >= 0x1p-500 && m <= 0x1p500) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull) return std::nan("");
 	return 1.0 / b;
+}
+// A sphere around a triangle for the walk's pre-test (grid_walk.hpp): a (ray, triangle) pair whose LINE passes the centre at more than
+//     sqrt(r2a + kb * |centre - origin|^2)
+// cannot pass triangle.rs:11-44 and is not tested.  What has to hold is that the reference's test, AS COMPUTED in binary64, fails for every pair
+// the pre-test drops.  In exact arithmetic the test accepts lines through the triangle, all of which pass within r of the centre of any sphere
+// that contains the three vertices.  As computed, the barycentric coordinates carry an error of at most ~4 eps |s| |h| / |a| with |a| >= 1e-8
+// (EPSILON), |h| <= L (longest edge) and |s| <= |centre - origin| + L: a point up to 4.4e-8 L^2 (|d| + L) outside the triangle can still be
+// accepted.  Both terms are taken a hundredfold: the radius grows by 4.4e-6 L^3 (and 1e-3 of itself, and an ulp-sized absolute term), the
+// allowance k |d| with k = 4.4e-6 L^2 enters through (r + k|d|)^2 <= 1.01 r^2 + 101 k^2 |d|^2, and 32 eps |d|^2 covers the cancellation in
+// |d|^2 - (d.rd)^2 of the pre-test itself.  The sphere is the smallest one around the vertices (the longest edge's, or the circumscribed one).
+inline void triangle_sphere(const double *p9, double out[4], double &kb) {
+	const double *P[3] = {p9, p9 + 3, p9 + 6};
+	auto sub = [](const double *a, const double *b, double *o) { for (int i = 0; i < 3; i++) o[i] = a[i] - b[i]; };
+	auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+	auto cross = [](const double *a, const double *b, double *o) { o[0] = a[1] * b[2] - a[2] * b[1], o[1] = a[2] * b[0] - a[0] * b[2], o[2] = a[0] * b[1] - a[1] * b[0]; };
+	double e[3][3], l2[3];
+	sub(P[2], P[1], e[0]), sub(P[0], P[2], e[1]), sub(P[1], P[0], e[2]); // edge i is opposite vertex i
+	for (int i = 0; i < 3; i++) l2[i] = dot(e[i], e[i]);
+	const int longest = l2[0] >= l2[1] && l2[0] >= l2[2] ? 0 : (l2[1] >= l2[2] ? 1 : 2);
+	const double L = std::sqrt(l2[longest]);
+	double c[3];
+	for (int i = 0; i < 3; i++) c[i] = 0.5 * (P[(longest + 1) % 3][i] + P[(longest + 2) % 3][i]);
+	double dv[3];
+	sub(P[longest], c, dv);
+	if (dot(dv, dv) > 0.25 * l2[longest]) { // acute: the circumscribed sphere's centre, A + (|b|^2 (a x b) x a + |a|^2 b x (a x b)) / (2 |a x b|^2)
+		double a[3], b[3], n[3], t1[3], t2[3];
+		sub(P[1], P[0], a), sub(P[2], P[0], b), cross(a, b, n);
+		const double n2 = dot(n, n);
+		cross(n, a, t1), cross(b, n, t2);
+		if (n2 > 0.0 && std::isfinite(n2))
+			for (int i = 0; i < 3; i++) c[i] = P[0][i] + (dot(b, b) * t1[i] + dot(a, a) * t2[i]) / (2.0 * n2);
+	}
+	double r2 = 0.0;
+	for (int v = 0; v < 3; v++) { // whatever the centre came out as: the radius that contains the vertices
+		sub(P[v], c, dv);
+		r2 = std::max(r2, dot(dv, dv));
+	}
+	const double cmax = std::max(std::fabs(c[0]), std::max(std::fabs(c[1]), std::fabs(c[2])));
+	const double r = std::sqrt(r2) * 1.001 + 4.4e-6 * L * L * L + 1e-12 * (1.0 + cmax);
+	out[0] = c[0], out[1] = c[1], out[2] = c[2], out[3] = 1.01 * r * r;
+	const double k = 4.4e-6 * L * L;
+	kb = 101.0 * k * k + 32.0 * 2.220446049250313e-16;
+	if (!(std::isfinite(out[0]) && std::isfinite(out[1]) && std::isfinite(out[2]) && std::isfinite(out[3]) && std::isfinite(kb)))
+		out[0] = out[1] = out[2] = 0.0, out[3] = std::numeric_limits<double>::infinity(), kb = 0.0; // a triangle with non-finite vertices: never dropped
 }
 inline void triangle_aux(const double *p9, double out[4]) {
 	auto dist = [](const double *a, const double *b) {

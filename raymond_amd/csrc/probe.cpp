@@ -223,6 +223,16 @@ rmd_status rmd_probe_grid_intersect(rmd_context *ctx, const rmd_scene *scene, ui
 	return scene_probe(ctx, scene, 1, g, n, ray6, hit, t, tri);
 }
 
+rmd_status rmd_probe_triangle_sphere(size_t n, const double *pos9, double *out5) {
+	if (n != 0 && (!pos9 || !out5)) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "probe: bad argument");
+	for (size_t i = 0; i < n; i++) {
+		double kb = 0.0;
+		rmd::triangle_sphere(pos9 + i * 9, out5 + i * 5, kb);
+		out5[i * 5 + 4] = kb;
+	}
+	return RMD_OK;
+}
+
 rmd_status rmd_probe_trace_samples(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *settings,
                                    size_t n, const uint32_t *xy2, const uint32_t *sample, double *rgb_out, int32_t *path_obj,
                                    uint32_t *path_sub) {

@@ -30,6 +30,7 @@ _SIGS = {
     "rmd_probe_scene_intersect": [_vp, _vp, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_grid_intersect": [_vp, _vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_trace_samples": [_vp, _vp, _P(abi.Camera), _P(abi.Settings), _sz, _vp, _vp, _vp, _vp, _vp],
+    "rmd_probe_triangle_sphere": [_sz, _vp, _vp],
 }
 PATH_STRIDE = 17
 _ready = False
@@ -157,3 +158,16 @@ def trace_samples(ctx, dscene, cam, settings, xy, samples, paths=False):
                                   _p(po) if paths else None, _p(ps) if paths else None)
     )
     return (rgb, po, ps) if paths else rgb
+
+
+def triangle_sphere(pos9):
+    """Host only (no GPU): the pre-test sphere of each triangle -> (centre float64[n, 3], r2a float64[n], kb float64[n]); api: rmd_probe_triangle_sphere."""
+    from . import abi as _abi
+
+    L = _L()
+    pos9 = _f(pos9, 9)
+    out = np.zeros((pos9.shape[0], 5))
+    st = L.rmd_probe_triangle_sphere(pos9.shape[0], _p(pos9), _p(out))
+    if st != _abi.RMD_OK:
+        raise RuntimeError("rmd_probe_triangle_sphere: status %d" % st)
+    return out[:, :3], out[:, 3], out[:, 4]
