@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RMD_ABI_VERSION 4u
+#define RMD_ABI_VERSION 5u
 
 typedef int32_t rmd_status;
 enum {
@@ -235,7 +235,10 @@ enum {
 	RMD_TUNE_AXIS_PAIRS = 8,   /* RMD_AXIS_PAIRS: read by rmd_scene_create — pairs of opposite planes whose normals are exactly +e_k / -e_k (the walls of an
 	                              axis-aligned room) tested with one component of the ray: 0 = the library's choice (yes, in scenes of regular
 	                              parameters), 1 = never (every pair takes the general test: same samples, bit for bit)                      */
-	RMD_TUNE_COUNT = 9
+	RMD_TUNE_PATH_QUEUES = 9,  /* RMD_PATH_QUEUES: persistent split launches of scenes with grids keep their paths in queues in device memory — ray
+	                              compaction between bounces: a wave's trips are 64 new samples, 64 parked hits or one grid walk for 64 parked rays
+	                              (rmd_launch_info.queued): 0 = the library's choice (yes), 1 = never (a lane keeps its path: same samples, bit for bit) */
+	RMD_TUNE_COUNT = 10
 };
 /* Free and total memory of the context's device, bytes (hipMemGetInfo): what a host that shares the GPU sizes its launches by. */
 rmd_status rmd_context_memory_info(rmd_context *ctx, uint64_t *out_free_bytes, uint64_t *out_total_bytes);
@@ -313,6 +316,8 @@ typedef struct rmd_launch_info {
 	                             wave tile: short launches of scenes with grids), 0 = direct mode (lane = pixel, no scratch)               */
 	uint32_t chained;         /* 1 = persistent waves drew their next work item while the last paths of the current one finished (short
 	                             split launches of scenes with grids; RMD_TUNE_CHAIN_ITEMS)                                                */
+	uint32_t queued;          /* 1 = the paths lived in per-wave queues in device memory and every trip of a wave served lanes that all needed
+	                             the same thing (persistent split launches of scenes with grids; RMD_TUNE_PATH_QUEUES; ABI 5)            */
 } rmd_launch_info;
 rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out);
 

@@ -7,7 +7,7 @@ compiled library.
 """
 import ctypes as C
 
-RMD_ABI_VERSION = 4
+RMD_ABI_VERSION = 5
 
 RMD_OK = 0
 RMD_ERR_INVALID_ARGUMENT = 1
@@ -41,7 +41,7 @@ RMD_RENDER_DOF = 1  # rmd_settings.flags
 RMD_RENDER_TRACE_BLACK_PATHS = 2  # never end a zero-throughput path early
 RMD_RENDER_END_BLACK_PATHS = 4  # end them in scenes with grids too (flags 0: only where provably exact, i.e. scenes without grids)
 (RMD_TUNE_SAMPLE_SPLIT, RMD_TUNE_WALK_BATCH, RMD_TUNE_MASK_BUDGET, RMD_TUNE_LAUNCH_FORM, RMD_TUNE_SCRATCH_CAP_MB, RMD_TUNE_WALK_CUT,
- RMD_TUNE_SPLIT_MIN_SAMPLES, RMD_TUNE_CHAIN_ITEMS, RMD_TUNE_AXIS_PAIRS) = range(9)
+ RMD_TUNE_SPLIT_MIN_SAMPLES, RMD_TUNE_CHAIN_ITEMS, RMD_TUNE_AXIS_PAIRS, RMD_TUNE_PATH_QUEUES) = range(10)
 RMD_LAUNCH_AUTO, RMD_LAUNCH_PER_ITEM, RMD_LAUNCH_PERSISTENT = range(3)
 RMD_COMM_ID_BYTES = 128
 
@@ -125,4 +125,5 @@ class LaunchInfo(C.Structure):  # rmd_launch_info
         ("waves_per_workgroup", C.c_uint32),
         ("buffered", C.c_uint32),
         ("chained", C.c_uint32),
+        ("queued", C.c_uint32),
     ]

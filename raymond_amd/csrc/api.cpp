@@ -71,6 +71,7 @@ rmd_status context_create(int32_t device, hipStream_t stream, bool own_stream, r
 		ctx->tunable[RMD_TUNE_SPLIT_MIN_SAMPLES] = env_int("RMD_SPLIT_MIN_SAMPLES");
 		ctx->tunable[RMD_TUNE_CHAIN_ITEMS] = env_int("RMD_CHAIN_ITEMS");
 		ctx->tunable[RMD_TUNE_AXIS_PAIRS] = env_int("RMD_AXIS_PAIRS");
+		ctx->tunable[RMD_TUNE_PATH_QUEUES] = env_int("RMD_PATH_QUEUES");
 		const char *form = std::getenv("RMD_LAUNCH_FORM");
 		ctx->tunable[RMD_TUNE_LAUNCH_FORM] = !form ? 0 : (std::strcmp(form, "per-item") == 0 || std::strcmp(form, "1") == 0) ? 1 : (std::strcmp(form, "persistent") == 0 || std::strcmp(form, "2") == 0) ? 2 : 0;
 #if RMD_DIAG
@@ -179,7 +180,8 @@ rmd_status check_fault(rmd_context *ctx) {
 	if (code & kFaultSortedTripLoop) what += " trip loop of render_wave_sorted;";
 	if (code & kFaultWorkLoop) what += " work loop of a persistent workgroup;";
 	if (code & kFaultWalkRounds) what += " round loop of a grid walk;";
-	if (code & ~(kFaultTripLoop | kFaultSortedTripLoop | kFaultWorkLoop | kFaultWalkRounds)) what += " unknown code;";
+	if (code & kFaultQueuedTripLoop) what += " trip loop of render_wave_queued;";
+	if (code & ~(kFaultTripLoop | kFaultSortedTripLoop | kFaultWorkLoop | kFaultWalkRounds | kFaultQueuedTripLoop)) what += " unknown code;";
 	char num[96];
 	std::snprintf(num, sizeof(num), " %u wave(s) reported, the last one at work item %u (code 0x%x)", reports, item, code);
 	return fail(ctx, RMD_ERR_DEVICE_FAULT,
@@ -251,6 +253,7 @@ void rmd_context_destroy(rmd_context *ctx) {
 	if (ctx->d_sample_buf) (void)hipFree(ctx->d_sample_buf);
 	if (ctx->d_debug_counters) (void)hipFree(ctx->d_debug_counters);
 	if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+	if (ctx->d_queue_buf) (void)hipFree(ctx->d_queue_buf);
 	if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
 	if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
 	if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
@@ -764,6 +767,28 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			RMD_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));
 			Q.work_counter = ctx->d_work_counter;
 		}
+		// Persistent split launches of scenes with grids keep their paths in queues in device memory (render_kernel.hpp: render_wave_queued;
+		// RMD_TUNE_PATH_QUEUES: 1 = never): kQueuePaths entries on each of a resident wave's two stacks, 192 bytes a path — 49 KB a wave, 200 MB
+		// for the 4,096 resident waves of an MI355X — allocated at the first launch that wants them.  A device that cannot provide them runs
+		// the lane-per-path form (render_wave): the same frame bit for bit.
+		if (persistent_pass && buffered && scene->n_grids != 0u && ctx->tunable[RMD_TUNE_PATH_QUEUES] != 1) {
+			const size_t wave_bytes = rmd::path_queue_bytes_host(rmd::kQueuePaths), need = wave_bytes * ctx->wave_slots;
+			if (ctx->queue_buf_bytes < need) {
+				if (ctx->d_queue_buf) RMD_HIP(ctx, hipFree(ctx->d_queue_buf));
+				ctx->d_queue_buf = nullptr, ctx->queue_buf_bytes = 0;
+				const hipError_t qe = hipMalloc((void **)&ctx->d_queue_buf, need);
+				if (qe == hipSuccess) {
+					ctx->queue_buf_bytes = need;
+					// (zeroed once: a trip's idle lanes read the trip's first entry, never one nobody wrote — but a fresh allocation should not hold another process's data)
+					RMD_HIP(ctx, hipMemsetAsync(ctx->d_queue_buf, 0, need, ctx->stream));
+				} else {
+					(void)hipGetLastError();
+					ctx->d_queue_buf = nullptr;
+					if (qe != hipErrorOutOfMemory) return rmd::fail(ctx, RMD_ERR_HIP, std::string("hipMalloc(path queues): ") + hipGetErrorString(qe));
+				}
+			}
+			if (ctx->d_queue_buf) Q.queue_buf = ctx->d_queue_buf, Q.queue_wave_bytes = (uint32_t)wave_bytes, Q.queue_paths = rmd::kQueuePaths;
+		}
 		// spheres kernel: the wave that finishes a wave tile last adds the tile's samples to the pixels itself (no second kernel: 120.3 ->
 		// 117.0 ms per C2 frame).  Mesh scenes keep sum_kernel: their kernel waits on memory a third of the time, and the sum's 33 GB of
 		// streaming reads in between cost it more (491.4 vs 487.3 ms on C3) than the separate kernel's 5.5 ms
@@ -781,7 +806,8 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		RMD_HIP(ctx, rmd::launch_render_tiles(ctx->stream, Q, scene->d_objects, scene->d_grids, ctx->d_wave_tiles, accum_dev, persistent_pass ? ctx->n_cus : 0u, &shape));
 		ctx->last_launch.passes++, ctx->last_launch.split_k = Q.split_k, ctx->last_launch.buffered = Q.buffered;
 		ctx->last_launch.persistent = shape.persistent, ctx->last_launch.waves_per_workgroup = shape.waves_per_wg; // the form it was launched in, not the one asked for
-		ctx->last_launch.chained = shape.persistent ? Q.chain_items : 0u;
+		ctx->last_launch.queued = shape.queued;
+		ctx->last_launch.chained = (shape.persistent && !shape.queued) ? Q.chain_items : 0u;
 		if (settings->sample_count == 0) break;
 	}
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));

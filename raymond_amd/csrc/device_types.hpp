@@ -125,12 +125,17 @@ struct RenderParams {
 	uint32_t _pad2;                     //   tested ahead of the object loop (kObjAxisPair), 0 = none
 	uint32_t *fault;                    // the context's fault words (host memory mapped into the device's address space; kFault*): a wave whose loop runs past
 	                                    // its bound reports here, poisons work_counter so that the launch drains, and leaves (render_kernel.hpp: report_fault)
+	unsigned char *queue_buf;           // split launches of grid scenes in the persistent form (render_kernel.hpp: render_wave_queued): the waves' path queues in
+	                                    // device memory, queue_wave_bytes per resident wave (wave = blockIdx.x * waves per workgroup + wave of the workgroup); null = the
+	uint32_t queue_wave_bytes;          // lane-per-path form
+	uint32_t queue_paths;               // paths a wave may have in flight (capacity of each of its queues)
 };
 // Fault words: [0] OR of the kFault* codes, [1] the work item (or list entry) of the wave that reported last, [2] number of reports.
 constexpr uint32_t kFaultTripLoop = 1u;       // render_wave's trip loop (lane-per-path form: direct mode, the mesh kernel, the list probes)
 constexpr uint32_t kFaultSortedTripLoop = 2u; // render_wave_sorted's trip loop (role-sorted spheres kernel)
 constexpr uint32_t kFaultWorkLoop = 4u;       // a persistent wave drew more work items than the launch has
 constexpr uint32_t kFaultWalkRounds = 8u;     // a grid walk call ran more rounds than a ray can take steps (grid_walk.hpp)
+constexpr uint32_t kFaultQueuedTripLoop = 16u; // render_wave_queued's trip loop (the mesh kernel with its paths in queues)
 constexpr uint32_t kFaultWords = 4u;
 constexpr uint32_t kWorkCounterPoison = 0x80000000u; // OR-ed into the work counter by a faulting wave: every later draw is past the last item (items are < 2^31: api.cpp)
 

@@ -39,6 +39,8 @@ struct rmd_context {
 	uint32_t n_cus = 0;
 	size_t hbm_bytes = 0; // totalGlobalMem of the device
 	uint32_t *d_work_counter = nullptr; // next work item of a persistent launch (render_kernel.hpp)
+	unsigned char *d_queue_buf = nullptr; // the resident waves' path queues (render_kernel.hpp: render_wave_queued), allocated at the first launch that uses them
+	size_t queue_buf_bytes = 0;
 	uint32_t *d_tile_done = nullptr;    // split launches: finished waves per wave tile (render_kernel.hpp)
 	size_t tile_done_words = 0;
 	unsigned long long *d_debug_counters = nullptr; // walk diagnostics (DIAG builds, RMD_DEBUG=8|16)

@@ -94,8 +94,15 @@ constexpr size_t kSortPoolBytes = 84u * RMD_SORT_SLOTS; // per-wave LDS (sizeof(
 constexpr size_t kWaveHeadBytes = 16u;
 // the form a render launch was made in (render_kernel.hpp: launch_render) -> rmd_launch_info
 struct LaunchShape {
-	uint32_t persistent = 0, waves_per_wg = 0;
+	uint32_t persistent = 0, waves_per_wg = 0, queued = 0, resident_waves = 0;
 };
+// paths a wave of the queued form may have in flight (render_kernel.hpp: render_wave_queued; at least 192, a multiple of 64)
+#ifndef RMD_QUEUE_PATHS
+#define RMD_QUEUE_PATHS 256
+#endif
+constexpr uint32_t kQueuePaths = RMD_QUEUE_PATHS;
+inline size_t path_queue_bytes_host(uint32_t cap) { return (size_t)cap * (9u * 8u + 10u * 8u + 5u * 4u + 5u * 4u); } // (render_kernel.hpp: path_queue_bytes)
+static_assert(kQueuePaths >= 192u && kQueuePaths % 64u == 0u, "two stacks short of a full trip + the 64 paths of a generation trip");
 size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg);
 uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total);
 // n_cus > 0 and P.work_counter set: grid scenes run as persistent workgroups (render_kernel.hpp)

@@ -911,6 +911,290 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 	finish_sample_range(P, tile, wt, lane, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Split launches of scenes WITH grids, persistent form (the mesh kernel): PATH QUEUES — ray compaction between bounces.
+//
+// In render_wave() a lane keeps its path from its first ray to its last vertex.  On a mesh scene a third of a trip's lanes then sit on a ray
+// that waits for the wave's next grid walk, the others run a merged shade / primary-ray stream of which each needs one half, and a walk serves
+// the ~36 lanes that happen to wait: the trips — half of the kernel's vector instructions — issue at 40 % lanes.
+// Round 4's repair (tools/experiments/mesh_sorted_trips.patch) kept the wave's paths in a pool in LDS and lost more in resident waves (12 for 16)
+// than the fuller trips gained: the LDS is spoken for by the occupancy masks and the walk scratch.  Here the paths live in DEVICE MEMORY — two
+// dense stacks per resident wave, private to it (no atomics, nothing shared; the top of a stack is what the wave wrote last, so it is read back
+// from the XCD's L2) — and a lane holds a path only for the length of one trip.  A trip is one of three kinds, each with up to 64 lanes that all
+// need the same thing:
+//   GEN    the work item's next 64 (pixel, sample) pairs: primary ray (src/trace.rs:322-333, thin lens :335-360), planes / spheres / grid boxes;
+//   SHADE  the top 64 parked hits: shading (:256-319) -> bounce ray, planes / spheres / grid boxes;
+//   WALK   the top 64 parked rays — rays that enter a grid's box: ONE cooperative walk (grid_walk.hpp), merged with the ray's closest plane /
+//          sphere hit (core/src/scene.rs:54-74: the lexicographic minimum of (distance, object index)).
+// A ray of a GEN / SHADE trip that enters no box is classified on the spot; one that does is pushed onto the ray stack (origin, direction, its
+// closest plane / sphere hit so far, the path's throughput and RNG state).  Classification (:242-252 and the rules of DESIGN.md section 3) ends a
+// path — its sample goes to its 32-byte sector of the per-sample buffer — or pushes the hit (point, normal, throughput, RNG state) onto the hit
+// stack.  A path's arithmetic is the same functions on the same values in the same order as in render_wave(): every sample has the same bits;
+// which lane and which trip compute it changes nothing (the RNG is keyed by pixel and sample, sum_kernel adds the samples in order).
+// A path carries its pixel, sample and scratch sector with it, so the wave draws its next work item as soon as the current one has no pair left
+// (as render_wave<.., CHAIN> does) and only the launch's last paths are finished in trips that are not full.
+struct PathQueues { // one resident wave's queues: SoA, `cap` entries each (a multiple of 64: every field is 512-byte aligned)
+	RMD_GLOBAL double *hit_d;   // [9][cap]: hit point, surface normal, throughput
+	RMD_GLOBAL double *ray_d;   // [10][cap]: origin, direction, throughput, distance of the closest plane / sphere hit so far (kFMax: none)
+	RMD_GLOBAL uint32_t *hit_w; // [5][cap]: object | next RNG block << 16; lobe bits | depth << 24; x | y << 16; sample; scratch sector
+	RMD_GLOBAL uint32_t *ray_w; // [5][cap]: (closest plane / sphere + 1, 0 = none) | next RNG block << 16; then as above
+	uint32_t cap;
+};
+__host__ __device__ inline size_t path_queue_bytes(uint32_t cap) { return (size_t)cap * (9u * 8u + 10u * 8u + 5u * 4u + 5u * 4u); }
+constexpr uint32_t kQueuedTripBoundPerPath = 2u * RMD_MAX_BOUNCE_LIMIT_DEV + 4u; // trips per path, as if ONE lane ran them all: a segment is at most a SHADE and a WALK trip
+// LDS of a wave of the queued form: the walk scratch and the ring of the walk's pre-test (grid_walk.hpp: the first 1 KB of a WalkCarry), then the head
+constexpr size_t kQueuedRingBytes = 128u * sizeof(unsigned long long);
+__host__ __device__ inline size_t queued_wave_lds_bytes() { return sizeof(WalkScratch) + kQueuedRingBytes + kWaveHeadBytes; }
+
+RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_params, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids,
+                                const void *__restrict__ work, const DevObject *lobjs, const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first_item) {
+	const uint32_t lane = threadIdx.x & 63u;
+	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds);
+	WalkCarry *ring = reinterpret_cast<WalkCarry *>(wave_lds + sizeof(WalkScratch)); // (only its first kQueuedRingBytes exist: no walk is put aside here)
+	if (P.bounce_limit == 0u) return; // (such launches are not made: api.cpp)
+	PathQueues q;
+	{
+		const uint32_t cap = P.queue_paths;
+		RMD_GLOBAL unsigned char *base = (RMD_GLOBAL unsigned char *)P.queue_buf + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * P.queue_wave_bytes;
+		q.cap = cap;
+		q.hit_d = (RMD_GLOBAL double *)base;
+		q.ray_d = q.hit_d + (size_t)9u * cap;
+		q.hit_w = (RMD_GLOBAL uint32_t *)(q.ray_d + (size_t)10u * cap);
+		q.ray_w = q.hit_w + (size_t)5u * cap;
+	}
+	const V3 cam_pos = ld3(P.cam_pos);
+	enum { kGen = 0, kShade = 1, kWalk = 2 };
+
+	// the work item the wave hands pairs out of (wave-uniform); pool_items = 0xFFFFFFFF: the launch has no item left
+	uint32_t wt = 0, pool_first = 0, pool_items = 0, next_item = 0;
+	WaveTile tile = {};
+	auto take_item = [&](const RenderParams &Q, uint32_t drawn) {
+		wt = drawn / Q.split_k;
+		const uint32_t part = drawn - wt * Q.split_k;
+		tile = reinterpret_cast<const WaveTile *>(work)[wt];
+		const uint32_t per_part = (Q.sample_count + Q.split_k - 1u) / Q.split_k;
+		const uint32_t s_lo = part * per_part < Q.sample_count ? part * per_part : Q.sample_count;
+		const uint32_t s_hi = s_lo + per_part < Q.sample_count ? s_lo + per_part : Q.sample_count;
+		pool_first = s_lo, pool_items = (s_hi - s_lo) * 64u, next_item = 0u;
+	};
+	if (first_item / P.split_k < P.n_work) take_item(P, first_item);
+	uint32_t n_hit = 0, n_ray = 0; // wave-uniform: entries on the two stacks
+	// The trip loop's bound (report_fault).  Every trip hands out 64 pairs or takes at least one path off a stack and either ends it or moves it on
+	// by half a segment (WALK: ray -> hit or end; SHADE: hit -> ray, hit or end), a path has at most RMD_MAX_BOUNCE_LIMIT segments, and at most
+	// cap paths are in flight when an item is drawn: an item's pairs + cap paths, times kQueuedTripBoundPerPath, is more trips than the wave can
+	// take before its next draw even if every trip served ONE lane.  The count starts again at every draw.
+	unsigned long long trips_left = ((unsigned long long)pool_items + q.cap) * kQueuedTripBoundPerPath + 64ull;
+#if RMD_DIAG
+	if (P.debug_flags & 32u) trips_left = 1ull; // tests/test_gpu_faults.py: forces the bound
+#endif
+	for (;;) {
+		// the launch parameters a trip needs, re-read from the kernel arguments (see render_wave)
+		KernargWords src = kernarg_params;
+		asm volatile("" : "+s"(src));
+		unsigned long long w[sizeof(RenderParams) / 8];
+#pragma unroll
+		for (unsigned i = 0; i < sizeof(RenderParams) / 8; i++) w[i] = src[i];
+		RenderParams Pt;
+		__builtin_memcpy(&Pt, w, sizeof(Pt));
+
+		// the item's pool has run dry: the wave draws its next work item (the persistent work loop's draw, render_kernel below, with the same bound)
+		if (next_item >= pool_items && pool_items != 0xFFFFFFFFu) {
+			volatile uint32_t *last_draw = reinterpret_cast<volatile uint32_t *>(wave_lds + queued_wave_lds_bytes() - kWaveHeadBytes);
+			uint32_t drawn = 0, floor = 0;
+			if (lane == 0u) {
+				drawn = atomicAdd(Pt.work_counter, 1u);
+				floor = *last_draw;
+				*last_draw = drawn + 1u;
+			}
+			drawn = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+			floor = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor);
+#if RMD_DIAG
+			if ((Pt.debug_flags & 128u) && floor != 0u) floor = 0xFFFFFFFFu; // tests/test_gpu_faults.py: forces the bound at a wave's second draw
+#endif
+			if (drawn >= Pt.n_work * Pt.split_k) {
+				pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
+			} else {
+				if (RMD_UNLIKELY(drawn < floor)) report_fault(Pt, kFaultWorkLoop, drawn); // (never reached; the poisoned counter ends the launch)
+				take_item(Pt, drawn);
+				trips_left = ((unsigned long long)pool_items + q.cap) * kQueuedTripBoundPerPath + 64ull;
+#if RMD_DIAG
+				if (Pt.debug_flags & 32u) trips_left = 1ull;
+#endif
+			}
+		}
+		const bool pairs_left = next_item < pool_items; // (false once the launch has no item left: next_item = pool_items = 0xFFFFFFFF)
+		// Which kind of trip.  A FULL trip whenever a stack holds 64 entries — walks first: they are what the other kinds wait for —, else the item's
+		// next 64 pairs, and only when the launch has no pair left to hand out the fuller of the two stacks in a trip that is not full.
+		// Every reachable state takes a trip that makes progress: (1) n_ray >= 64 or n_hit >= 64: a full trip, 64 paths move on.  (2) both below 64
+		// and pairs left: fewer than 128 paths are in flight, the 64 a GEN trip may add fit (cap >= 192: api.cpp), next_item grows by 64 (all of
+		// them may fall outside a ragged tile: a trip without a lane, but the pool has shrunk).  (3) both below 64, no pair left, a stack
+		// non-empty: a trip of max(n_ray, n_hit) >= 1 lanes.  (4) both empty and no pair left: the loop ends.  A WALK trip always serves whatever
+		// rays wait (no ray ever waits for others to join it for ever), and no state selects a trip of a kind whose source is empty — the hang of
+		// round 4's three-list pool (tools/experiments/README.md) was such a state: a generation trip chosen with no free slot.
+		if (RMD_UNLIKELY(trips_left-- == 0ull)) { // (never reached: see above) — the wave reports, drops what it holds and leaves through the loop's own exit
+			report_fault(Pt, kFaultQueuedTripLoop, wt);
+			n_hit = 0u, n_ray = 0u, pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
+			break;
+		}
+		uint32_t kind;
+		if (n_ray >= 64u) kind = kWalk;
+		else if (n_hit >= 64u) kind = kShade;
+		else if (pairs_left) kind = kGen;
+		else if (n_ray != 0u && n_ray >= n_hit) kind = kWalk;
+		else if (n_hit != 0u) kind = kShade;
+		else break;
+
+		bool active, failed = false, classify, to_ray = false;
+		uint32_t depth = 1, lobe_bits = 0, rng_block = 0, pxw = 0, smp = 0, sector = 0, sub = 0;
+		int oi = -1;
+		double t;
+		V3 ro, rd, T;
+		RMD_UNDEF(t) RMD_UNDEF3(ro) RMD_UNDEF3(rd) RMD_UNDEF3(T)
+		if (kind == kWalk) {
+			// ---------------- WALK: the top (up to) 64 parked rays, lane i the entry n_ray - n + i; one cooperative walk per grid object
+			const uint32_t n = n_ray < 64u ? n_ray : 64u, base = n_ray - n;
+			active = lane < n;
+			const uint32_t e = active ? base + lane : base; // (a lane beyond n reads the trip's first entry: sane values that nobody uses)
+			n_ray = base;
+			const uint32_t cap = q.cap;
+			ro = mk(q.ray_d[e], q.ray_d[cap + e], q.ray_d[2u * cap + e]);
+			rd = mk(q.ray_d[3u * cap + e], q.ray_d[4u * cap + e], q.ray_d[5u * cap + e]);
+			t = q.ray_d[9u * cap + e];
+			const uint32_t st = q.ray_w[e];
+			oi = (int)(st & 0xFFFFu) - 1;
+			rng_block = st >> 16;
+			intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, active, ro, rd, t, oi, sub, Pt.debug_flags, Pt.debug_counters, 0u, ring, nullptr, 0u);
+			// the rest of the path's state, fetched behind the walk (the popped entries stay where they are until the next push onto this stack)
+			T = mk(q.ray_d[6u * cap + e], q.ray_d[7u * cap + e], q.ray_d[8u * cap + e]);
+			const uint32_t lb = q.ray_w[cap + e];
+			lobe_bits = lb & 0x3FFFFFu, depth = lb >> 24;
+			pxw = q.ray_w[2u * cap + e], smp = q.ray_w[3u * cap + e], sector = q.ray_w[4u * cap + e];
+			classify = active;
+		} else {
+			Rng rng;
+			if (kind == kShade) {
+				// ---------------- SHADE: the top (up to) 64 parked hits
+				const uint32_t n = n_hit < 64u ? n_hit : 64u, base = n_hit - n;
+				active = lane < n;
+				const uint32_t e = active ? base + lane : base;
+				n_hit = base;
+				const uint32_t cap = q.cap;
+				const uint32_t st = q.hit_w[e], lb = q.hit_w[cap + e];
+				pxw = q.hit_w[2u * cap + e], smp = q.hit_w[3u * cap + e], sector = q.hit_w[4u * cap + e];
+				const V3 frag = mk(q.hit_d[e], q.hit_d[cap + e], q.hit_d[2u * cap + e]);
+				const V3 normal = mk(q.hit_d[3u * cap + e], q.hit_d[4u * cap + e], q.hit_d[5u * cap + e]);
+				T = mk(q.hit_d[6u * cap + e], q.hit_d[7u * cap + e], q.hit_d[8u * cap + e]);
+				rng.pixel = (pxw >> 16) * Pt.W + (pxw & 0xFFFFu), rng.sample = smp;
+				rng.block = st >> 16, rng.lobe_bits = lb & 0x3FFFFFu;
+				depth = lb >> 24;
+				const DevObject &o = lobjs[st & 0xFFFFu];
+				// (every lane shades — see render_wave_sorted)
+				shade(Pt, normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, ro, rd, T);
+				depth++;
+				// (see render_wave: a path whose throughput is exactly zero is ended where the caller asked for that)
+				const bool black = Pt.end_black_paths != 0u && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
+				failed = active && (depth > Pt.bounce_limit || black);
+			} else {
+				// ---------------- GEN: the work item's next 64 (pixel, sample) pairs, one per lane (slots outside a ragged tile are skipped)
+				const uint32_t k = next_item + lane;
+				next_item += 64u;
+				active = k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h;
+				const uint32_t x = tile.x0 + (k & 7u), y = tile.y0 + ((k >> 3) & 7u);
+				pxw = x | y << 16, smp = Pt.sample_begin + pool_first + (k >> 6);
+				sector = (wt * Pt.sample_count + pool_first + (k >> 6)) * 64u + (k & 63u); // (< 2^32: api.cpp caps a pass)
+				rng.pixel = y * Pt.W + x, rng.sample = smp, rng.block = 0u, rng.lobe_bits = 0u;
+				T = mk(1.0, 1.0, 1.0);
+				double u0, u1;
+				rng.next2(Pt.key0, Pt.key1, u0, u1); // block 0: the pixel jitter (:326-327)
+				primary_ray(Pt, x, y, u0, u1, ro, rd);
+				if (Pt.use_dof) failed = active && !thin_lens_from_pinhole(Pt, ro, rd, rng, ro, rd); // the reference panics there; the sample contributes zero
+			}
+			rng_block = rng.block, lobe_bits = rng.lobe_bits;
+			// ---------------- src/trace.rs:239, first part — planes, spheres and the grids' boxes (scene_split.hpp)
+			const bool want = active && !failed;
+			const bool enters = intersect_simple(objs, Pt.n_objects, grids, want, ro, rd, t, oi, Pt.axis_pairs);
+			to_ray = want && enters;
+			classify = want && !enters;
+		}
+#if RMD_DIAG
+		if ((Pt.debug_flags & 8u) && Pt.debug_counters) { // trips by kind and the lanes they serve
+			const unsigned long long am = __ballot(active);
+			if (lane == 0) atomicAdd(&Pt.debug_counters[10], 1ull), atomicAdd(&Pt.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&Pt.debug_counters[12], kind == kWalk ? (unsigned long long)__popcll(am) : 0ull);
+		}
+#endif
+		// ---------------- the rays that have to walk: pushed onto the ray stack, consecutive entries for the lanes that push
+		if (kind != kWalk) {
+			const unsigned long long pm = __ballot(to_ray);
+			if (pm != 0ull) {
+				const uint32_t cap = q.cap;
+				const uint32_t e = n_ray + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+				if (to_ray) {
+					q.ray_d[e] = ro.x, q.ray_d[cap + e] = ro.y, q.ray_d[2u * cap + e] = ro.z;
+					q.ray_d[3u * cap + e] = rd.x, q.ray_d[4u * cap + e] = rd.y, q.ray_d[5u * cap + e] = rd.z;
+					q.ray_d[6u * cap + e] = T.x, q.ray_d[7u * cap + e] = T.y, q.ray_d[8u * cap + e] = T.z;
+					q.ray_d[9u * cap + e] = t;
+					q.ray_w[e] = (uint32_t)(oi + 1) | (rng_block << 16); // (fewer than 2^16 objects fit the LDS; a lens loop runs at most 4096 rounds)
+					q.ray_w[cap + e] = lobe_bits | (depth << 24);
+					q.ray_w[2u * cap + e] = pxw, q.ray_w[3u * cap + e] = smp, q.ray_w[4u * cap + e] = sector;
+				}
+				n_ray += (uint32_t)__popcll(pm);
+			}
+		}
+		// ---------------- classification (the rules of render_wave's phase C)
+		bool terminal = failed, park = false, emitted = false;
+		V3 frag, normal;
+		RMD_UNDEF3(frag) RMD_UNDEF3(normal)
+		if (classify) {
+			if (oi < 0) {
+				terminal = true; // :242 miss -> radiance 0
+			} else {
+				const DevObject &o = lobjs[oi];
+				frag = ro + rd * t; // :246
+				if (o.material_kind == 2u) {
+					emitted = true; // :250-252 Emission
+					terminal = true;
+				} else {
+					if (o.geometry_kind == 0u) normal = ld3(o.normal);                        // plane.rs:28-32
+					else if (o.geometry_kind == 1u) normal = normalize(frag - ld3(o.origin)); // sphere.rs:31-35
+					else {
+						const DevGrid &g = grids[o.grid_index];
+						normal = triangle_normal(as_global(g.tri_pos) + (size_t)sub * 9, as_global(g.tri_nrm) + (size_t)sub * 9, as_global(g.tri_aux) + (size_t)sub * 4, frag); // acc_grid.rs:85-87
+					}
+					const double probe_sum = ((normal.x + normal.y) + normal.z) + ((frag.x + frag.y) + frag.z);
+					const bool finite_inputs = __builtin_fabs(probe_sum) < __builtin_inf();
+					const bool black_bounce = Pt.end_black_paths != 0u && (o.flags & kObjBlackDiffuse) != 0u && lobe_bits < (1u << 21);
+					if (((depth == Pt.bounce_limit && Pt.shade_last_depth == 0u) || black_bounce) && finite_inputs) terminal = true; // L = 0
+					else park = true;
+				}
+			}
+		}
+		if (terminal) { // the finished sample: T (.) L into its 32-byte sector of the per-sample buffer (added by sum_kernel, behind the kernel boundary)
+			V3 L = mk(0.0, 0.0, 0.0);
+			if (emitted) L = ld3(lobjs[oi].color); // (fetched here, outside the nest of branches that found the light)
+			L = hadamard(T, L);
+			RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (size_t)sector * kSampleStride;
+			dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+		}
+		// ---------------- the hits that go on: pushed onto the hit stack
+		{
+			const unsigned long long pm = __ballot(park);
+			if (pm != 0ull) {
+				const uint32_t cap = q.cap;
+				const uint32_t e = n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+				if (park) {
+					q.hit_d[e] = frag.x, q.hit_d[cap + e] = frag.y, q.hit_d[2u * cap + e] = frag.z;
+					q.hit_d[3u * cap + e] = normal.x, q.hit_d[4u * cap + e] = normal.y, q.hit_d[5u * cap + e] = normal.z;
+					q.hit_d[6u * cap + e] = T.x, q.hit_d[7u * cap + e] = T.y, q.hit_d[8u * cap + e] = T.z;
+					q.hit_w[e] = (uint32_t)oi | (rng_block << 16);
+					q.hit_w[cap + e] = lobe_bits | (depth << 24);
+					q.hit_w[2u * cap + e] = pxw, q.hit_w[3u * cap + e] = smp, q.hit_w[4u * cap + e] = sector;
+				}
+				n_hit += (uint32_t)__popcll(pm);
+			}
+		}
+	}
+}
+
 // PERSIST = false: one wave per work item, block b's waves take items b * waves .. ; PERSIST = true (tile modes of grid scenes):
 // as many 16-wave workgroups as the device has CUs, each staging the masks ONCE, whose waves draw work items from a launch-wide
 // counter (P.work_counter, zeroed by the host) until none is left — the masks cost one copy per CU instead of one per
@@ -923,11 +1207,17 @@ constexpr bool kSortedTrips = RMD_SORTED_TRIPS && MODE == kModeTilesBuffered && 
 template <int MODE, bool GRID>
 constexpr bool kChainItems = RMD_CHAIN_ITEMS && MODE == kModeTilesBuffered && GRID; // (persistent form only: render_wave, CHAIN)
 // LDS of one wave of an instantiation
+// QUEUED (persistent split launches of scenes with grids): the wave body with the paths in queues in device memory (render_wave_queued)
+#ifndef RMD_PATH_QUEUES
+#define RMD_PATH_QUEUES 1
+#endif
 template <int MODE, bool GRID>
-__host__ __device__ inline size_t wave_lds_of(uint32_t n_grids) { return kSortedTrips<MODE, GRID> ? kWaveHeadBytes + sizeof(SortPool) : wave_lds_bytes(n_grids); }
+constexpr bool kPathQueues = RMD_PATH_QUEUES && MODE == kModeTilesBuffered && GRID;
+template <int MODE, bool GRID, bool QUEUED = false>
+__host__ __device__ inline size_t wave_lds_of(uint32_t n_grids) { return QUEUED ? queued_wave_lds_bytes() : kSortedTrips<MODE, GRID> ? kWaveHeadBytes + sizeof(SortPool) : wave_lds_bytes(n_grids); }
 template <int MODE, bool GRID>
 constexpr uint32_t kPersistWaves = kSortedTrips<MODE, GRID> ? kSortedWavesPerWg : GRID ? kGridPersistWavesPerWg : kPersistWavesPerWg;
-template <int MODE, bool GRID, bool PERSIST, bool CHAIN = false>
+template <int MODE, bool GRID, bool PERSIST, bool CHAIN = false, bool QUEUED = false>
 __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ? 64 * kGridWavesPerWg : 64,
                              GRID ? RMD_GRID_MINW : (kSortedTrips<MODE, GRID>) ? (RMD_SORT_WAVES * RMD_SORT_WGS_PER_CU / 4) : (PERSIST ? 4 : RMD_NOGRID_MINW)) void render_kernel(
     RenderParams P, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids, const void *__restrict__ work, double *__restrict__ out,
@@ -944,8 +1234,8 @@ __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ?
 	// the data, not in front: the mesh kernel's register allocation is at its limit, and with the data 16 bytes further on it came out with 22
 	// spilled registers instead of 13.)
 	unsigned char *wave_lds = smem + (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
-	                          (size_t)wave * wave_lds_of<MODE, GRID>(P.n_grids);
-	[[maybe_unused]] unsigned char *wave_head = wave_lds + wave_lds_of<MODE, GRID>(P.n_grids) - kWaveHeadBytes;
+	                          (size_t)wave * wave_lds_of<MODE, GRID, QUEUED>(P.n_grids);
+	[[maybe_unused]] unsigned char *wave_head = wave_lds + wave_lds_of<MODE, GRID, QUEUED>(P.n_grids) - kWaveHeadBytes;
 	// stage the object table and the occupancy masks: coalesced, once per workgroup
 	{
 		const double *src = reinterpret_cast<const double *>(objs);
@@ -988,7 +1278,8 @@ __global__ __launch_bounds__(PERSIST ? 64 * (kPersistWaves<MODE, GRID>) : GRID ?
 				break;
 			}
 #endif
-			if constexpr (kSortedTrips<MODE, GRID>) render_wave_sorted(P, kernarg_params, objs, grids, work, out, lobjs, wave_lds, item);
+			if constexpr (QUEUED) render_wave_queued(P, kernarg_params, objs, grids, work, lobjs, lds_masks, wave_lds, item);
+			else if constexpr (kSortedTrips<MODE, GRID>) render_wave_sorted(P, kernarg_params, objs, grids, work, out, lobjs, wave_lds, item);
 			else render_wave<MODE, GRID, CHAIN>(P, kernarg_params, objs, grids, work, out, path_obj, path_sub, lobjs, lds_masks, wave_lds, item);
 		}
 	} else {
@@ -1005,8 +1296,10 @@ template <int MODE, bool GRID>
 inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const DevObject *objs, const DevGrid *grids, const void *work,
                                 uint32_t n_waves, double *out, int32_t *path_obj, uint32_t *path_sub, uint32_t n_cus = 0, LaunchShape *shape = nullptr) {
 	// LDS of a workgroup of `waves` waves of this instantiation: [object table][grid occupancy masks][per-wave area]
+	[[maybe_unused]] const bool queued = kPathQueues<MODE, GRID> && P.queue_buf != nullptr; // (api.cpp provides the queues for the launches that take this form)
 	auto lds_for = [&](uint32_t waves) {
-		return (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u + (size_t)waves * wave_lds_of<MODE, GRID>(P.mask_words_total ? 1u : 0u);
+		return (size_t)P.n_objects * sizeof(DevObject) + (size_t)((P.mask_words_total + 3u) & ~3u) * 4u +
+		       (size_t)waves * (queued ? wave_lds_of<MODE, GRID, true>(1u) : wave_lds_of<MODE, GRID>(P.mask_words_total ? 1u : 0u));
 	};
 	if constexpr (MODE != kModeList) {
 		uint32_t pw = kPersistWaves<MODE, GRID>;
@@ -1017,19 +1310,23 @@ inline hipError_t launch_render(hipStream_t stream, const RenderParams &P, const
 		if (n_cus != 0u && P.work_counter != nullptr && lds_for(pw) <= kLdsBudgetBytes) {
 			const size_t lds = lds_for(pw);
 			// short launches of scenes with grids: the instantiation whose waves chain their work items (render_wave, CHAIN)
-			const bool chain = kChainItems<MODE, GRID> && P.chain_items != 0u;
-			hipError_t e = hipFuncSetAttribute(chain ? reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true, (kChainItems<MODE, GRID>)>)
-			                                         : reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>),
+			const bool chain = kChainItems<MODE, GRID> && P.chain_items != 0u && !queued;
+			hipError_t e = hipFuncSetAttribute(queued  ? reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true, false, (kPathQueues<MODE, GRID>)>)
+			                                   : chain ? reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true, (kChainItems<MODE, GRID>)>)
+			                                           : reinterpret_cast<const void *>(&render_kernel<MODE, GRID, true>),
 			                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes);
 			if (e != hipSuccess) return e;
 			const uint32_t wgs = (n_waves + pw - 1u) / pw, resident = n_cus * (kSortedTrips<MODE, GRID> ? RMD_SORT_WGS_PER_CU : 1u);
-			if (chain)
+			if (queued)
+				hipLaunchKernelGGL((render_kernel<MODE, GRID, true, false, (kPathQueues<MODE, GRID>)>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs,
+				                   grids, work, out, path_obj, path_sub);
+			else if (chain)
 				hipLaunchKernelGGL((render_kernel<MODE, GRID, true, (kChainItems<MODE, GRID>)>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs,
 				                   grids, work, out, path_obj, path_sub);
 			else
 				hipLaunchKernelGGL((render_kernel<MODE, GRID, true>), dim3(wgs < resident ? wgs : resident), dim3(64u * pw), lds, stream, P, objs, grids, work, out,
 				                   path_obj, path_sub);
-			if (shape) shape->persistent = 1u, shape->waves_per_wg = pw;
+			if (shape) shape->persistent = 1u, shape->waves_per_wg = pw, shape->queued = queued ? 1u : 0u, shape->resident_waves = (wgs < resident ? wgs : resident) * pw;
 			return hipGetLastError();
 		}
 	}

@@ -10,7 +10,7 @@ txt = open(sys.argv[1]).read()
 for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.wavefront_size", txt, re.S):
     name, body = m.group(1), m.group(2)
     g = lambda k: (re.search(r"\.%s:\s+(\d+)" % k, body) or [0, "?"])[1]
-    short = re.sub(r"_ZN3rmd13render_kernelILi(\d)ELb(\d)ELb(\d)ELb(\d)EE.*", r"render_kernel<\1,\2,\3,\4>", name)
+    short = re.sub(r"_ZN3rmd13render_kernelILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)EE.*", r"render_kernel<\1,\2,\3,\4,\5>", name)
     short = re.sub(r"_ZN3rmd(\d+)([a-z_]+)E.*", lambda m: m.group(2)[: int(m.group(1))], short)
     print("%-28s vgpr %3s spill %3s sgpr %3s scratch %4s lds %5s" % (short[:28], g("vgpr_count"), g("vgpr_spill_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
 PY
