@@ -396,6 +396,14 @@ def main():
         },
     }
 
+    # who took part (N > 1): every rank's own view — its rank, the world size IT saw, its device and the samples of its tile share — gathered to rank 0
+    if dist is not None:
+        mine = {"rank": rank, "world_size_seen": int(dist.get_world_size()), "device": int(local_rank), "backend": backend,
+                "samples_per_step": int(main_run["my_samples"])}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        out["ranks"] = seen
+
     # for the record, beside `value`: the same frame with every path traced to its end as the reference does (RMD_RENDER_TRACE_BLACK_PATHS) —
     # the same checksum, the reference's full number of path segments
     if world == 1 and not args.no_roofline_leg and not args.lean:

@@ -21,7 +21,9 @@
  *
  * Conventions: plain C, POD structs, caller owns every buffer it passes, the
  * library owns the opaque handles.  Every function returns rmd_status
- * (0 = OK); nothing throws or aborts across the boundary (the reference's
+ * (0 = OK); nothing throws or aborts across the boundary — every entry point
+ * that allocates on the host runs behind a catch: std::bad_alloc comes back as
+ * RMD_ERR_OUT_OF_MEMORY (tests/test_abi.py forces it) — (the reference's
  * failure mode is a Rust panic — and a hang: `TaskHandle::await` polls a counter
  * that a panicked worker never decrements, src/trace.rs:82-92; here it is a
  * status + rmd_last_error()).  That holds inside the kernel too: every loop of
@@ -56,7 +58,9 @@ enum {
 	RMD_ERR_DEVICE_FAULT = 8      /* a loop of the render kernel ran past its bound (it cannot, for any input: an internal fault);
 	                                 the launch was cut short, the frame it wrote to is NOT valid; text in rmd_last_error.
 	                                 Reported by the first call that waits for the launch (rmd_render_tiles,
-	                                 rmd_context_synchronize, rmd_last_kernel_ms, rmd_framebuffer_download, rmd_reduce_framebuffer) */
+	                                 rmd_context_synchronize, rmd_last_kernel_ms, rmd_framebuffer_download[_tiles],
+	                                 rmd_framebuffer_upload_tiles, rmd_context_wait_transfers, rmd_resolve_tonemap,
+	                                 rmd_reduce_framebuffer) */
 };
 
 /* ---- scene description (mirrors core/src/scene.rs:8-45, core/src/lib.rs:21-26) ---- */
@@ -113,7 +117,11 @@ typedef struct rmd_grid_desc {
 	uint64_t n_tris;
 	const struct rmd_grid_build *built; /* NULL, or the rmd_grid_build these pointers belong to (set by rmd_grid_build_describe): rmd_scene_create
 	                                       then derives its device tables ONCE per build (about 50 ms of host time for 100k triangles) and
-	                                       every later upload of the same grid — one per render_tiled call and GPU — reuses them       */
+	                                       every later upload of the same grid — one per render_tiled call and GPU — reuses them.
+	                                       The pointer is only as good as the build: a caller that COPIES a description, or hands its arrays
+	                                       to another owner, and lets the copy outlive rmd_grid_build_destroy must set `built` to NULL in
+	                                       the copy (the arrays then only have to stay valid for the duration of rmd_scene_create, as in
+	                                       ABI 3).  A struct that was zero-initialised and filled by hand has NULL here.                  */
 } rmd_grid_desc;
 
 /* CameraSettings (src/trace.rs:32-40) + Transform (src/transform.rs:4-7, position only). */

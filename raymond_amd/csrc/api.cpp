@@ -165,6 +165,19 @@ rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text) {
 	return status;
 }
 
+rmd_status fail_noexcept(rmd_context *ctx, rmd_status status, const char *what, const char *text) noexcept {
+	try {
+		return fail(ctx, status, std::string(what) + ": " + text);
+	} catch (...) { // not even the message: the status alone
+		try {
+			if (ctx) ctx->last_error.clear();
+			tl_last_error.clear();
+		} catch (...) {
+		}
+		return status;
+	}
+}
+
 static_assert(RMD_MAX_BOUNCE_LIMIT_DEV == RMD_MAX_BOUNCE_LIMIT, "launch.hpp mirrors include/raymond_hip.h");
 
 // Called after every wait for the context's stream.  The words are host memory: two loads when nothing happened.
@@ -226,6 +239,7 @@ RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const r
 		uint32_t k = rmd::kWalkCutDefault;
 		if (ctx && ctx->tunable[RMD_TUNE_WALK_CUT] > 0) k = (uint32_t)std::min<int64_t>(ctx->tunable[RMD_TUNE_WALK_CUT] - 1, 31); // any value gives the same image
 		P.walk_cut = (scene && scene->n_grid_objects == 1u) ? (k | (2u * k) << 8) : 0u;
+		P.walk_steps_bound = scene ? scene->walk_steps_bound : 0u;
 	}
 #if RMD_DIAG
 	if (ctx) P.debug_flags = ctx->debug_flags;
@@ -521,6 +535,7 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 			d.bbox_min[a] = g.bbox_min[a], d.bbox_max[a] = g.bbox_max[a], d.cell_size[a] = g.cell_size[a];
 			d.inv_cell_size[a] = rmd::exact_reciprocal(g.cell_size[a]);
 			d.res[a] = g.resolution[a];
+			if (a == 2) sc->walk_steps_bound = std::max<uint32_t>(sc->walk_steps_bound, (uint32_t)std::min<uint64_t>((uint64_t)g.resolution[0] + g.resolution[1] + g.resolution[2] + 3u, 0xFFFFFFFFull));
 		}
 		d.n_cells = g.n_cells, d.n_tris = g.n_tris;
 		uint64_t last_nonempty = 0;
@@ -682,8 +697,8 @@ static uint32_t choose_split(const rmd_context *ctx, bool has_grid, uint32_t n_w
 	return k;
 }
 
-rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
-                                  const rmd_tile_rect *tiles, uint32_t n_tiles, double *accum_dev) {
+static rmd_status render_tiles_async_impl(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
+                                          const rmd_tile_rect *tiles, uint32_t n_tiles, double *accum_dev) {
 	if (rmd_status s = bind(ctx)) return s;
 	if (rmd_status s = check_render_args(ctx, scene, camera, settings)) return s;
 	if (!accum_dev || (n_tiles && !tiles)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_render_tiles: null tiles/accum pointer");
@@ -730,7 +745,9 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		if (sectors_per_sample * per_pass > 0xFFFFFFFFull) per_pass = (uint32_t)(0xFFFFFFFFull / sectors_per_sample);
 		if (per_pass < 8u) per_pass = 8u;
 		if (per_pass > P.sample_count) per_pass = P.sample_count;
-		while (bytes_per_sample * per_pass > ctx->sample_buf_bytes) {
+		// (a frame of more than 2^32 / 8 / 64 = 8.4 M wave tiles — 537 Mpixel — cannot number even the smallest pass's sectors in 32 bits: unsplit, no scratch)
+		if (sectors_per_sample * per_pass > 0xFFFFFFFFull) split = 1u, buffered = false, per_pass = P.sample_count;
+		while (buffered && bytes_per_sample * per_pass > ctx->sample_buf_bytes) {
 			double *fresh = nullptr;
 			const hipError_t e = hipMalloc((void **)&fresh, bytes_per_sample * per_pass);
 			if (e == hipSuccess) {
@@ -816,7 +833,12 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 		unsigned long long h[24];
 		RMD_HIP(ctx, hipMemcpyAsync(h, ctx->d_debug_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
 		RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		if (P.debug_flags & 16u)
+		if ((P.debug_flags & 16u) && ctx->last_launch.queued) {
+			static const char *kinds[3] = {"GEN  ", "SHADE", "WALK "};
+			for (int k = 0; k < 3; k++)
+				std::fprintf(stderr, "[rmd queued stamps, cycles] %s trips=%llu fetch=%llu make_ray=%llu simple=%llu walk=%llu ray_push=%llu classify=%llu stores=%llu\n", kinds[k], h[k * 8 + 7],
+				             h[k * 8 + 0], h[k * 8 + 1], h[k * 8 + 2], h[k * 8 + 3], h[k * 8 + 4], h[k * 8 + 5], h[k * 8 + 6]);
+		} else if (P.debug_flags & 16u)
 			std::fprintf(stderr, "[rmd stamps, cycles] wave_total=%llu next_ray=%llu simple=%llu walk=%llu classify=%llu | walk: init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
 			             h[0], h[1], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
 		else
@@ -826,6 +848,12 @@ rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, cons
 			std::fprintf(stderr, "[rmd debug] sphere pre-test: pairs passed=%llu full chunks=%llu | pairs dropped that pass the reference's test (flag 64; must be 0)=%llu\n", h[17], h[18], h[16]);
 	}
 	return RMD_OK;
+}
+
+rmd_status rmd_render_tiles_async(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *camera, const rmd_settings *settings,
+                                  const rmd_tile_rect *tiles, uint32_t n_tiles, double *accum_dev) {
+	// (the wave-tile table and the cached rectangle list are std::vectors: nothing throws across the boundary)
+	return rmd::guarded(ctx, "rmd_render_tiles", [&] { return render_tiles_async_impl(ctx, scene, camera, settings, tiles, n_tiles, accum_dev); });
 }
 
 rmd_status rmd_context_set_tunable(rmd_context *ctx, uint32_t key, int64_t value) {
@@ -918,8 +946,8 @@ rmd_status wait_slot(rmd_context *ctx, rmd_context::TransferSlot &sl) {
 }
 } // namespace
 
-rmd_status rmd_framebuffer_download_tiles_async(rmd_context *ctx, const double *dev, uint32_t width, uint32_t height, const rmd_tile_rect *rects,
-                                                uint32_t n_rects, double *host_packed) {
+static rmd_status download_tiles_async_impl(rmd_context *ctx, const double *dev, uint32_t width, uint32_t height, const rmd_tile_rect *rects,
+                                            uint32_t n_rects, double *host_packed) {
 	if (rmd_status s = bind(ctx)) return s;
 	if (!dev || !host_packed || (n_rects && !rects) || width == 0 || height == 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_download_tiles: bad argument");
 	if (n_rects == 0) return RMD_OK;
@@ -941,6 +969,11 @@ rmd_status rmd_framebuffer_download_tiles_async(rmd_context *ctx, const double *
 	return RMD_OK;
 }
 
+rmd_status rmd_framebuffer_download_tiles_async(rmd_context *ctx, const double *dev, uint32_t width, uint32_t height, const rmd_tile_rect *rects,
+                                                uint32_t n_rects, double *host_packed) {
+	return rmd::guarded(ctx, "rmd_framebuffer_download_tiles", [&] { return download_tiles_async_impl(ctx, dev, width, height, rects, n_rects, host_packed); });
+}
+
 rmd_status rmd_context_wait_transfers(rmd_context *ctx) {
 	if (rmd_status s = bind(ctx)) return s;
 	for (auto &sl : ctx->transfer)
@@ -954,8 +987,8 @@ rmd_status rmd_framebuffer_download_tiles(rmd_context *ctx, const double *dev, u
 	return rmd_context_wait_transfers(ctx);
 }
 
-rmd_status rmd_framebuffer_upload_tiles(rmd_context *ctx, const double *host_packed, double *dev, uint32_t width, uint32_t height,
-                                        const rmd_tile_rect *rects, uint32_t n_rects) {
+static rmd_status upload_tiles_impl(rmd_context *ctx, const double *host_packed, double *dev, uint32_t width, uint32_t height,
+                                    const rmd_tile_rect *rects, uint32_t n_rects) {
 	if (rmd_status s = bind(ctx)) return s;
 	if (!dev || !host_packed || (n_rects && !rects) || width == 0 || height == 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_framebuffer_upload_tiles: bad argument");
 	if (n_rects == 0) return RMD_OK;
@@ -970,7 +1003,11 @@ rmd_status rmd_framebuffer_upload_tiles(rmd_context *ctx, const double *host_pac
 	RMD_HIP(ctx, hipMemcpyAsync(sl.d_packed, host_packed, (size_t)n_pixels * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 	RMD_HIP(ctx, rmd::launch_tile_copy(ctx->stream, false, dev, sl.d_packed, d_rects, d_first, n_rects, width));
 	RMD_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the caller's buffer and the table are free again
-	return RMD_OK;
+	return rmd::check_fault(ctx); // (this wait has also waited for every render enqueued before it)
+}
+rmd_status rmd_framebuffer_upload_tiles(rmd_context *ctx, const double *host_packed, double *dev, uint32_t width, uint32_t height,
+                                        const rmd_tile_rect *rects, uint32_t n_rects) {
+	return rmd::guarded(ctx, "rmd_framebuffer_upload_tiles", [&] { return upload_tiles_impl(ctx, host_packed, dev, width, height, rects, n_rects); });
 }
 
 rmd_status rmd_host_alloc(rmd_context *ctx, size_t bytes, void **out_host) {
@@ -1002,8 +1039,8 @@ rmd_status rmd_last_launch_info(const rmd_context *ctx, rmd_launch_info *out) {
 	return RMD_OK;
 }
 
-rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32_t width, uint32_t height, uint32_t sample_count,
-                               double exposure, double gamma, uint8_t *out_rgb8_host) {
+static rmd_status resolve_tonemap_impl(rmd_context *ctx, const double *accum_dev, uint32_t width, uint32_t height, uint32_t sample_count,
+                                       double exposure, double gamma, uint8_t *out_rgb8_host, uint8_t *&d) {
 	if (rmd_status s = bind(ctx)) return s;
 	if (!accum_dev || !out_rgb8_host || width == 0 || height == 0 || sample_count == 0)
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_resolve_tonemap: bad argument");
@@ -1011,7 +1048,6 @@ rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32
 	if (n_pixels > 0xFFFFFFFFull) return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_resolve_tonemap: more than 2^32-1 pixels");
 	// device buffer: [rgb8: 3 n bytes, padded to 4][count: 1 word][flagged pixel indices: n words]
 	const size_t rgb_bytes = (n_pixels * 3 + 3) & ~(size_t)3;
-	uint8_t *d = nullptr;
 	RMD_HIP(ctx, hipMalloc((void **)&d, rgb_bytes + 4 + n_pixels * 4));
 	uint32_t *d_count = reinterpret_cast<uint32_t *>(d + rgb_bytes), *d_list = d_count + 1;
 	const double sc = (double)sample_count, inv_gamma = 1.0 / gamma;
@@ -1050,9 +1086,16 @@ rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32
 			for (int c = 0; c < 3; c++) out_rgb8_host[i * 3 + c] = ok ? (uint8_t)v[c] : (uint8_t)0;
 		}
 	}
-	(void)hipFree(d);
 	RMD_HIP(ctx, e);
-	return RMD_OK;
+	// the frame came from launches this call has waited for: one that was cut short by a device fault is not handed out as an image
+	return rmd::check_fault(ctx);
+}
+rmd_status rmd_resolve_tonemap(rmd_context *ctx, const double *accum_dev, uint32_t width, uint32_t height, uint32_t sample_count,
+                               double exposure, double gamma, uint8_t *out_rgb8_host) {
+	uint8_t *d = nullptr; // the device scratch: freed here whichever way the body leaves
+	const rmd_status s = rmd::guarded(ctx, "rmd_resolve_tonemap", [&] { return resolve_tonemap_impl(ctx, accum_dev, width, height, sample_count, exposure, gamma, out_rgb8_host, d); });
+	if (d) (void)hipFree(d);
+	return s;
 }
 
 } // extern "C"

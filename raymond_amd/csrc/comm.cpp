@@ -91,7 +91,7 @@ rmd_status rmd_comm_unique_id(uint8_t id_out[RMD_COMM_ID_BYTES]) {
 	return RMD_OK;
 }
 
-rmd_status rmd_comm_create(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES], int32_t rank, int32_t world_size, rmd_comm **out) {
+static rmd_status comm_create_impl(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES], int32_t rank, int32_t world_size, rmd_comm **out) {
 	if (!ctx || !id || !out || world_size < 1 || rank < 0 || rank >= world_size)
 		return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_comm_create: bad argument");
 	Rccl &r = rccl();
@@ -115,6 +115,10 @@ rmd_status rmd_comm_create(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES]
 	}
 	*out = c;
 	return RMD_OK;
+}
+rmd_status rmd_comm_create(rmd_context *ctx, const uint8_t id[RMD_COMM_ID_BYTES], int32_t rank, int32_t world_size, rmd_comm **out) {
+	if (out) *out = nullptr;
+	return rmd::guarded(ctx, "rmd_comm_create", [&] { return comm_create_impl(ctx, id, rank, world_size, out); }); // (the loader's error texts are strings)
 }
 
 void rmd_comm_destroy(rmd_comm *comm) {

@@ -129,6 +129,8 @@ struct RenderParams {
 	                                    // device memory, queue_wave_bytes per resident wave (wave = blockIdx.x * waves per workgroup + wave of the workgroup); null = the
 	uint32_t queue_wave_bytes;          // lane-per-path form
 	uint32_t queue_paths;               // paths a wave may have in flight (capacity of each of its queues)
+	uint32_t walk_steps_bound;          // most steps a ray's walk can take in any grid of the scene (res.x + res.y + res.z + 3: grid_walk.hpp) — a walk that is put
+	uint32_t _pad3;                     //   aside takes part in one WALK trip per step at worst: part of render_wave_queued's trip bound
 };
 // Fault words: [0] OR of the kFault* codes, [1] the work item (or list entry) of the wave that reported last, [2] number of reports.
 constexpr uint32_t kFaultTripLoop = 1u;       // render_wave's trip loop (lane-per-path form: direct mode, the mesh kernel, the list probes)

@@ -40,10 +40,10 @@ inline uint64_t as_usize(double v) {
 
 } // namespace
 
-extern "C" rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const double *tri_nrm, uint64_t n_tris, rmd_grid_build **out) {
+static rmd_status grid_build_from_mesh_impl(const double *tri_pos, const double *tri_nrm, uint64_t n_tris, rmd_grid_build **out, rmd_grid_build *&g) {
 	if (!tri_pos || !tri_nrm || !out || n_tris == 0) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_grid_build_from_mesh: null/empty input");
 	if (n_tris >= (1ull << 32)) return rmd::fail(nullptr, RMD_ERR_UNSUPPORTED, "rmd_grid_build_from_mesh: more than 2^32-1 triangles");
-	rmd_grid_build *g = new (std::nothrow) rmd_grid_build();
+	g = new (std::nothrow) rmd_grid_build();
 	if (!g) return rmd::fail(nullptr, RMD_ERR_OUT_OF_MEMORY, "rmd_grid_build_from_mesh: allocation failed");
 
 	// Mesh::find_mesh_bounds (mesh.rs:123-140)
@@ -64,12 +64,10 @@ extern "C" rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const doub
 	uint64_t res[3];
 	for (int a = 0; a < 3; a++) res[a] = as_usize(std::fabs(size[a]) * density);
 	if (res[0] == 0 || res[1] == 0 || res[2] == 0 || res[0] > 0xFFFFFFFFull || res[1] > 0xFFFFFFFFull || res[2] > 0xFFFFFFFFull) {
-		delete g;
 		return rmd::fail(nullptr, RMD_ERR_GRID_INDEX, "grid resolution has a zero axis (reference underflows `grid_res[i] - 1`, acc_grid.rs:54)");
 	}
 	const uint64_t n_cells = res[0] * res[1] * res[2];
 	if (n_cells > (1ull << 31)) {
-		delete g;
 		return rmd::fail(nullptr, RMD_ERR_UNSUPPORTED, "grid has more than 2^31 cells");
 	}
 	for (int a = 0; a < 3; a++) {
@@ -89,7 +87,6 @@ extern "C" rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const doub
 		for (int a = 0; a < 3; a++) {
 			uint64_t lo, hi;
 			if (!to_usize((mn[a] - g->bbox_min[a]) / g->cell_size[a], lo) || !to_usize((mx[a] - g->bbox_min[a]) / g->cell_size[a], hi)) {
-				delete g;
 				return rmd::fail(nullptr, RMD_ERR_GRID_INDEX, "cell bound does not fit usize (reference: \"Failed to cast cell bounds to usize\", acc_grid.rs:44-51)");
 			}
 			ranges[i].lo[a] = (uint32_t)(lo < res[a] - 1 ? lo : res[a] - 1);
@@ -101,7 +98,6 @@ extern "C" rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const doub
 				for (uint64_t x = r.lo[0]; x <= r.hi[0]; x++) {
 					uint64_t idx = x + res[0] * (y + z * res[2]); // :61 — res.z where res.y is meant
 					if (idx >= n_cells) {
-						delete g;
 						return rmd::fail(nullptr, RMD_ERR_GRID_INDEX, "cell index past the cell array (reference panics at acc_grid.rs:61)");
 					}
 					count[idx]++;
@@ -116,7 +112,6 @@ extern "C" rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const doub
 		total += 1ull + count[c];
 	}
 	if (total > 0xFFFFFFFFull) {
-		delete g;
 		return rmd::fail(nullptr, RMD_ERR_UNSUPPORTED, "mapping_table exceeds 2^32 entries");
 	}
 	g->mapping.assign(total, 0u);
@@ -135,7 +130,17 @@ extern "C" rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const doub
 	g->pos.assign(tri_pos, tri_pos + n_tris * 9);
 	g->nrm.assign(tri_nrm, tri_nrm + n_tris * 9);
 	*out = g;
+	g = nullptr; // handed over
 	return RMD_OK;
+}
+// (the per-cell lists are a std::vector of std::vectors over every cell: nothing throws across the boundary — a mesh whose tables the host cannot
+// hold comes back as RMD_ERR_OUT_OF_MEMORY where the reference's `Vec` would abort the process)
+extern "C" rmd_status rmd_grid_build_from_mesh(const double *tri_pos, const double *tri_nrm, uint64_t n_tris, rmd_grid_build **out) {
+	if (out) *out = nullptr;
+	rmd_grid_build *g = nullptr;
+	const rmd_status s = rmd::guarded(nullptr, "rmd_grid_build_from_mesh", [&] { return grid_build_from_mesh_impl(tri_pos, tri_nrm, n_tris, out, g); });
+	delete g; // (whatever a failed build has left)
+	return s;
 }
 
 extern "C" rmd_status rmd_grid_build_describe(const rmd_grid_build *g, rmd_grid_desc *d) {

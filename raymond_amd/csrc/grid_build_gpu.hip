@@ -181,8 +181,7 @@ struct Dev {
 
 } // namespace
 
-extern "C" rmd_status rmd_grid_build_from_mesh_gpu(rmd_context *ctx, const double *tri_pos, const double *tri_nrm, uint64_t n_tris,
-                                                   rmd_grid_build **out) {
+static rmd_status grid_build_from_mesh_gpu_impl(rmd_context *ctx, const double *tri_pos, const double *tri_nrm, uint64_t n_tris, rmd_grid_build **out) {
 	if (!ctx) return rmd::fail(nullptr, RMD_ERR_INVALID_ARGUMENT, "rmd_grid_build_from_mesh_gpu: null context");
 	if (!tri_pos || !tri_nrm || !out || n_tris == 0) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "rmd_grid_build_from_mesh_gpu: null/empty input");
 	if (n_tris >= (1ull << 32)) return rmd::fail(ctx, RMD_ERR_UNSUPPORTED, "rmd_grid_build_from_mesh_gpu: more than 2^32-1 triangles");
@@ -267,4 +266,10 @@ extern "C" rmd_status rmd_grid_build_from_mesh_gpu(rmd_context *ctx, const doubl
 	g->nrm.assign(tri_nrm, tri_nrm + n_tris * 9);
 	*out = g.release();
 	return RMD_OK;
+}
+// (host vectors for the partial bounds and the downloaded tables, device buffers behind RAII: nothing throws across the boundary)
+extern "C" rmd_status rmd_grid_build_from_mesh_gpu(rmd_context *ctx, const double *tri_pos, const double *tri_nrm, uint64_t n_tris,
+                                                   rmd_grid_build **out) {
+	if (out) *out = nullptr;
+	return rmd::guarded(ctx, "rmd_grid_build_from_mesh_gpu", [&] { return grid_build_from_mesh_gpu_impl(ctx, tri_pos, tri_nrm, n_tris, out); });
 }

@@ -73,6 +73,7 @@ struct rmd_scene {
 	uint32_t n_grid_objects = 0; // objects whose geometry is a grid
 	uint32_t mask_words_total = 0; // LDS words of the grids' occupancy masks
 	uint32_t axis_pairs = 0; // RenderParams::axis_pairs
+	uint32_t walk_steps_bound = 0; // RenderParams::walk_steps_bound
 	bool regular = true; // every parameter the kernel reads is finite and inside the class for which ending zero-throughput paths is exact (api.cpp: rmd_scene_create)
 	rmd::DevObject *d_objects = nullptr;
 	rmd::DevGrid *d_grids = nullptr;
@@ -161,6 +162,23 @@ inline void triangle_aux(const double *p9, double out[4]) {
 }
 // Records `text` as the last error of `ctx` (or of the calling thread when ctx is null) and returns `status`.
 rmd_status fail(rmd_context *ctx, rmd_status status, const std::string &text);
+// The same for a caller that must not throw (the catch blocks of `guarded`): when even the message cannot be stored the status still comes back.
+rmd_status fail_noexcept(rmd_context *ctx, rmd_status status, const char *what, const char *text) noexcept;
+// "Nothing throws or aborts across the boundary" (include/raymond_hip.h): every extern "C" entry point that allocates with throwing containers
+// (std::vector, std::string) runs its body through this — std::bad_alloc becomes RMD_ERR_OUT_OF_MEMORY, anything else RMD_ERR_HIP with the
+// exception's text; the caller's process (a Rust or ctypes host) is never terminated by an unwinding C++ exception.
+template <class F>
+rmd_status guarded(rmd_context *ctx, const char *what, F &&body) noexcept {
+	try {
+		return body();
+	} catch (const std::bad_alloc &) {
+		return fail_noexcept(ctx, RMD_ERR_OUT_OF_MEMORY, what, "the host ran out of memory");
+	} catch (const std::exception &e) {
+		return fail_noexcept(ctx, RMD_ERR_HIP, what, e.what());
+	} catch (...) {
+		return fail_noexcept(ctx, RMD_ERR_HIP, what, "unknown exception");
+	}
+}
 #ifdef RMD_WITH_HIP
 // After a wait for the context's stream: RMD_ERR_DEVICE_FAULT (and the fault words cleared) when a wave of a launch reported one, else RMD_OK.
 rmd_status check_fault(rmd_context *ctx);

@@ -935,34 +935,68 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 // (as render_wave<.., CHAIN> does) and only the launch's last paths are finished in trips that are not full.
 struct PathQueues { // one resident wave's queues: SoA, `cap` entries each (a multiple of 64: every field is 512-byte aligned)
 	RMD_GLOBAL double *hit_d;   // [9][cap]: hit point, surface normal, throughput
-	RMD_GLOBAL double *ray_d;   // [10][cap]: origin, direction, throughput, distance of the closest plane / sphere hit so far (kFMax: none)
+	RMD_GLOBAL double *ray_d;   // [13][cap]: origin, direction, throughput, distance of the closest plane / sphere hit so far (kFMax: none); t_max of a walk put aside
 	RMD_GLOBAL uint32_t *hit_w; // [5][cap]: object | next RNG block << 16; lobe bits | depth << 24; x | y << 16; sample; scratch sector
-	RMD_GLOBAL uint32_t *ray_w; // [5][cap]: (closest plane / sphere + 1, 0 = none) | next RNG block << 16; then as above
-	uint32_t cap;
+	RMD_GLOBAL uint32_t *ray_w; // [10][cap]: (closest plane / sphere + 1, 0 = none) | next RNG block << 16; then as above, kRayCarried in the second word:
+	uint32_t cap;               //   the ray's walk was put aside (grid_walk.hpp: WalkCarry) and its cell index, previous cell and exit counters follow
 };
-__host__ __device__ inline size_t path_queue_bytes(uint32_t cap) { return (size_t)cap * (9u * 8u + 10u * 8u + 5u * 4u + 5u * 4u); }
+constexpr uint32_t kRayCarried = 1u << 23; // (the lobe bits are 22, the depth sits in the top byte)
+__host__ __device__ inline size_t path_queue_bytes(uint32_t cap) { return (size_t)cap * (9u * 8u + 13u * 8u + 5u * 4u + 10u * 4u); }
 constexpr uint32_t kQueuedTripBoundPerPath = 2u * RMD_MAX_BOUNCE_LIMIT_DEV + 4u; // trips per path, as if ONE lane ran them all: a segment is at most a SHADE and a WALK trip
-// LDS of a wave of the queued form: the walk scratch and the ring of the walk's pre-test (grid_walk.hpp: the first 1 KB of a WalkCarry), then the head
-constexpr size_t kQueuedRingBytes = 128u * sizeof(unsigned long long);
-__host__ __device__ inline size_t queued_wave_lds_bytes() { return sizeof(WalkScratch) + kQueuedRingBytes + kWaveHeadBytes; }
+// LDS of a wave of the queued form: the walk scratch, the walk's carry area (grid_walk.hpp: WalkCarry — during a call the ring of its pre-test; around a
+// call the DDA states of the walks it takes up / puts aside, on their way from / to the ray stack), per lane what a walking path does not need
+// during its walk (throughput, RNG state: 32 bytes a lane), then the head — 7,184 bytes: 16 waves beside the benchmark mesh's 36.7 KB of masks
+#ifndef RMD_QUEUE_SIDE_ALL
+#define RMD_QUEUE_SIDE_ALL 1 // 1: pixel, sample and sector wait in LDS too (44 bytes a lane: 15 waves beside the benchmark mesh's masks) instead of being fetched again behind the walk
+#endif
+constexpr size_t kQueuedSideBytes = 64u * (3u * sizeof(double) + (RMD_QUEUE_SIDE_ALL ? 5u : 2u) * sizeof(uint32_t));
+__host__ __device__ inline size_t queued_wave_lds_bytes() { return sizeof(WalkScratch) + sizeof(WalkCarry) + kQueuedSideBytes + kWaveHeadBytes; }
 
+// Queue traffic is non-temporal (RMD_QUEUE_NT): an entry is written once and read once, the waves' working set is several times the L2, and what it
+// displaces there are the scene's tables, which every walk gathers from (measured with plain accesses: L2 hit rate 73 -> 59 %, mean L1 -> L2 read
+// latency 227 -> 373 cycles against the lane-per-path form).
+#ifndef RMD_QUEUE_NT
+#define RMD_QUEUE_NT 0
+#endif
+#ifndef RMD_SAMPLE_NT
+#define RMD_SAMPLE_NT 1
+#endif
+template <class T>
+RMD_DEV T qld(const RMD_GLOBAL T *p) {
+#if RMD_QUEUE_NT
+	return __builtin_nontemporal_load(p);
+#else
+	return *p;
+#endif
+}
+template <class T, class U>
+RMD_DEV void qst(RMD_GLOBAL T *p, U v) {
+#if RMD_QUEUE_NT
+	__builtin_nontemporal_store((T)v, p);
+#else
+	*p = (T)v;
+#endif
+}
 RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_params, const DevObject *__restrict__ objs, const DevGrid *__restrict__ grids,
                                 const void *__restrict__ work, const DevObject *lobjs, const uint32_t *lds_masks, unsigned char *wave_lds, uint32_t first_item) {
 	const uint32_t lane = threadIdx.x & 63u;
 	WalkScratch &scr = *reinterpret_cast<WalkScratch *>(wave_lds);
-	WalkCarry *ring = reinterpret_cast<WalkCarry *>(wave_lds + sizeof(WalkScratch)); // (only its first kQueuedRingBytes exist: no walk is put aside here)
+	WalkCarry *carry = reinterpret_cast<WalkCarry *>(wave_lds + sizeof(WalkScratch));
+	// what a walking path does not need during its walk waits in LDS, one column per lane (the walk is where the kernel's register pressure peaks)
+	double *side_d = reinterpret_cast<double *>(wave_lds + sizeof(WalkScratch) + sizeof(WalkCarry)) + lane;                             // [0], [64], [128]: throughput
+	uint32_t *side_w = reinterpret_cast<uint32_t *>(wave_lds + sizeof(WalkScratch) + sizeof(WalkCarry) + 192u * sizeof(double)) + lane; // [0], [64]: the entry's first two words
 	if (P.bounce_limit == 0u) return; // (such launches are not made: api.cpp)
-	PathQueues q;
+	PathQueues q; // (the capacity is a constant of the build — api.cpp sizes the buffer by the same one — so the four arrays are ONE base address and constant offsets)
 	{
-		const uint32_t cap = P.queue_paths;
-		RMD_GLOBAL unsigned char *base = (RMD_GLOBAL unsigned char *)P.queue_buf + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * P.queue_wave_bytes;
+		constexpr uint32_t cap = kQueuePaths;
+		const uint32_t wave_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+		RMD_GLOBAL unsigned char *base = (RMD_GLOBAL unsigned char *)P.queue_buf + (size_t)wave_index * path_queue_bytes(cap);
 		q.cap = cap;
 		q.hit_d = (RMD_GLOBAL double *)base;
 		q.ray_d = q.hit_d + (size_t)9u * cap;
-		q.hit_w = (RMD_GLOBAL uint32_t *)(q.ray_d + (size_t)10u * cap);
+		q.hit_w = (RMD_GLOBAL uint32_t *)(q.ray_d + (size_t)13u * cap);
 		q.ray_w = q.hit_w + (size_t)5u * cap;
 	}
-	const V3 cam_pos = ld3(P.cam_pos);
 	enum { kGen = 0, kShade = 1, kWalk = 2 };
 
 	// the work item the wave hands pairs out of (wave-uniform); pool_items = 0xFFFFFFFF: the launch has no item left
@@ -982,11 +1016,26 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 	// The trip loop's bound (report_fault).  Every trip hands out 64 pairs or takes at least one path off a stack and either ends it or moves it on
 	// by half a segment (WALK: ray -> hit or end; SHADE: hit -> ray, hit or end), a path has at most RMD_MAX_BOUNCE_LIMIT segments, and at most
 	// cap paths are in flight when an item is drawn: an item's pairs + cap paths, times kQueuedTripBoundPerPath, is more trips than the wave can
-	// take before its next draw even if every trip served ONE lane.  The count starts again at every draw.
-	unsigned long long trips_left = ((unsigned long long)pool_items + q.cap) * kQueuedTripBoundPerPath + 64ull;
+	// take before its next draw even if every trip served ONE lane.  A walk that is put aside (below) goes back onto the ray stack and takes part in
+	// another WALK trip: every such trip moves it on by at least one step, of which it has at most walk_steps_bound.  The count starts again at every draw.
+	const unsigned long long trips_per_path = kQueuedTripBoundPerPath + (unsigned long long)RMD_MAX_BOUNCE_LIMIT_DEV * P.walk_steps_bound;
+	unsigned long long trips_left = ((unsigned long long)pool_items + q.cap) * trips_per_path + 64ull;
 #if RMD_DIAG
 	if (P.debug_flags & 32u) trips_left = 1ull; // tests/test_gpu_faults.py: forces the bound
 #endif
+	// Hits HELD in their lanes (RMD_QUEUE_HOLD_HITS).  A hit that a trip has classified goes onto the hit stack and comes back off it for the SHADE trip
+	// that takes it — 92 bytes written and 92 read through an L2 that the queues' working set overflows several times (measured: L2 hit rate
+	// 73 -> 59 %, L1 -> L2 read latency 227 -> 373 cycles against the lane-per-path form).  When the very next trip is a SHADE trip anyway — no full
+	// walk waits, and the stack's hits and this trip's together fill a trip — this trip's hits stay where they are, in their lanes' registers, and
+	// the SHADE trip pops only what it needs to fill the other lanes.  Same trips, same lanes per trip; a hit's values are the ones it would have
+	// read back.
+#ifndef RMD_QUEUE_HOLD_HITS
+#define RMD_QUEUE_HOLD_HITS 1
+#endif
+	bool held = false;
+	V3 h_frag, h_normal, h_T;
+	RMD_UNDEF3(h_frag) RMD_UNDEF3(h_normal) RMD_UNDEF3(h_T)
+	uint32_t h_st = 0, h_lb = 0, h_px = 0, h_smp = 0, h_sector = 0;
 	for (;;) {
 		// the launch parameters a trip needs, re-read from the kernel arguments (see render_wave)
 		KernargWords src = kernarg_params;
@@ -1016,7 +1065,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			} else {
 				if (RMD_UNLIKELY(drawn < floor)) report_fault(Pt, kFaultWorkLoop, drawn); // (never reached; the poisoned counter ends the launch)
 				take_item(Pt, drawn);
-				trips_left = ((unsigned long long)pool_items + q.cap) * kQueuedTripBoundPerPath + 64ull;
+				trips_left = ((unsigned long long)pool_items + q.cap) * trips_per_path + 64ull;
 #if RMD_DIAG
 				if (Pt.debug_flags & 32u) trips_left = 1ull;
 #endif
@@ -1036,8 +1085,29 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			n_hit = 0u, n_ray = 0u, pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
 			break;
 		}
+#if RMD_DIAG
+		// where a wave's time goes, by kind of trip and phase (RMD_DEBUG = 16; every stamp drains the memory counters first: what a phase has
+		// requested is charged to it) — debug_counters[kind * 8 + phase]: 0 = the trip's entries fetched, 1 = shading / ray generation,
+		// 2 = planes, spheres and boxes, 3 = the walk, 4 = ray pushes, 5 = classification, 6 = sample stores and hit pushes, 7 = trips
+		const bool qstamp = (Pt.debug_flags & 16u) && Pt.debug_counters;
+		unsigned long long qt_prev = qstamp ? __builtin_amdgcn_s_memtime() : 0ull;
+#define RMD_QSTAMP(phase)                                                                        \
+		if (qstamp) {                                                                                \
+			__builtin_amdgcn_s_waitcnt(0);                                                           \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
+			if (lane == 0u) atomicAdd(&Pt.debug_counters[kind * 8u + (phase)], now_ - qt_prev);      \
+			qt_prev = __builtin_amdgcn_s_memtime();                                                  \
+		}
+#else
+#define RMD_QSTAMP(phase)
+#endif
 		uint32_t kind;
-		if (n_ray >= 64u) kind = kWalk;
+		// (the stacks' counters are wave-uniform by construction; said once per trip, because with the held hits in the loop the compiler's uniformity
+		// analysis gives up on them and keeps them — and every address and branch made from them — in vector registers)
+		n_hit = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_hit), n_ray = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_ray);
+		const unsigned long long held_mask = RMD_QUEUE_HOLD_HITS ? __ballot(held) : 0ull;
+		if (held_mask != 0ull) kind = kShade; // (decided when the hits were held: the stack's hits and the held ones fill the trip)
+		else if (n_ray >= 64u) kind = kWalk;
 		else if (n_hit >= 64u) kind = kShade;
 		else if (pairs_left) kind = kGen;
 		else if (n_ray != 0u && n_ray >= n_hit) kind = kWalk;
@@ -1056,40 +1126,81 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			active = lane < n;
 			const uint32_t e = active ? base + lane : base; // (a lane beyond n reads the trip's first entry: sane values that nobody uses)
 			n_ray = base;
-			const uint32_t cap = q.cap;
-			ro = mk(q.ray_d[e], q.ray_d[cap + e], q.ray_d[2u * cap + e]);
-			rd = mk(q.ray_d[3u * cap + e], q.ray_d[4u * cap + e], q.ray_d[5u * cap + e]);
-			t = q.ray_d[9u * cap + e];
-			const uint32_t st = q.ray_w[e];
+			constexpr uint32_t cap = kQueuePaths;
+			ro = mk(qld(&q.ray_d[e]), qld(&q.ray_d[cap + e]), qld(&q.ray_d[2u * cap + e]));
+			rd = mk(qld(&q.ray_d[3u * cap + e]), qld(&q.ray_d[4u * cap + e]), qld(&q.ray_d[5u * cap + e]));
+			t = qld(&q.ray_d[9u * cap + e]);
+			const uint32_t st = qld(&q.ray_w[e]), lb = qld(&q.ray_w[cap + e]);
 			oi = (int)(st & 0xFFFFu) - 1;
-			rng_block = st >> 16;
-			intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, active, ro, rd, t, oi, sub, Pt.debug_flags, Pt.debug_counters, 0u, ring, nullptr, 0u);
-			// the rest of the path's state, fetched behind the walk (the popped entries stay where they are until the next push onto this stack)
-			T = mk(q.ray_d[6u * cap + e], q.ray_d[7u * cap + e], q.ray_d[8u * cap + e]);
-			const uint32_t lb = q.ray_w[cap + e];
-			lobe_bits = lb & 0x3FFFFFu, depth = lb >> 24;
-			pxw = q.ray_w[2u * cap + e], smp = q.ray_w[3u * cap + e], sector = q.ray_w[4u * cap + e];
-			classify = active;
+			RMD_QSTAMP(0u)
+			// the rest of the path's state goes from its entry to the lane's column of the side area, and comes back behind the walk
+			side_d[0] = qld(&q.ray_d[6u * cap + e]), side_d[64] = qld(&q.ray_d[7u * cap + e]), side_d[128] = qld(&q.ray_d[8u * cap + e]);
+			side_w[0] = st, side_w[64] = lb;
+#if RMD_QUEUE_SIDE_ALL
+			side_w[128] = qld(&q.ray_w[2u * cap + e]), side_w[192] = qld(&q.ray_w[3u * cap + e]), side_w[256] = qld(&q.ray_w[4u * cap + e]);
+#endif
+			// Walks put aside (grid_walk.hpp: cut_lanes): a call with many walkers stops stepping under its last K rays and ends under its last 2K
+			// walkers; what is left of such a walk — its DDA state — goes back onto the ray stack with the ray (kRayCarried) and the walk goes on in
+			// the trip that pops it, beside that trip's new rays.  The state travels through the wave's WalkCarry in LDS, lane by lane, the way
+			// render_wave's walks hand it from one call to the next.
+			bool carried = active && (lb & kRayCarried) != 0u;
+			if (__ballot(carried) != 0ull) {
+				if (carried) {
+					carry->tm[0][lane] = qld(&q.ray_d[10u * cap + e]), carry->tm[1][lane] = qld(&q.ray_d[11u * cap + e]), carry->tm[2][lane] = qld(&q.ray_d[12u * cap + e]);
+					carry->idx[lane] = qld(&q.ray_w[5u * cap + e]), carry->prev[lane] = qld(&q.ray_w[6u * cap + e]);
+					carry->rem[0][lane] = qld(&q.ray_w[7u * cap + e]), carry->rem[1][lane] = qld(&q.ray_w[8u * cap + e]), carry->rem[2][lane] = qld(&q.ray_w[9u * cap + e]);
+				}
+			}
+			const bool cut = n >= kWalkCutMinWalkers; // (every walker of such a call takes at least one step: walks always finish)
+			const uint32_t cut_lanes = cut ? Pt.walk_cut & 0xffu : 0u, cut_round = cut ? (Pt.walk_cut >> 8) & 0xffu : 0u;
+			intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, active, ro, rd, t, oi, sub, Pt.debug_flags & ~16u /* (this body's own stamps use the counters) */, Pt.debug_counters, cut_lanes, carry, &carried, cut_round);
+			RMD_QSTAMP(3u)
+			T = mk(side_d[0], side_d[64], side_d[128]);
+			rng_block = side_w[0] >> 16;
+			const uint32_t lb2 = side_w[64];
+			lobe_bits = lb2 & 0x3FFFFFu, depth = lb2 >> 24;
+			// (pixel, sample and sector are not needed before the trip's stores: fetched from the entry here — it stays as it is until this trip's own pushes —
+			// with the classification to arrive under)
+#if RMD_QUEUE_SIDE_ALL
+			pxw = side_w[128], smp = side_w[192], sector = side_w[256];
+#else
+			const uint32_t e2 = n_ray + (active ? lane : 0u); // (= e, made again: one register fewer across the walk)
+			pxw = qld(&q.ray_w[2u * cap + e2]), smp = qld(&q.ray_w[3u * cap + e2]), sector = qld(&q.ray_w[4u * cap + e2]);
+#endif
+			to_ray = carried; // an unfinished walk: back onto the stack (its closest plane / sphere hit is unchanged: a walk that has found nothing yet merges nothing)
+			classify = active && !carried;
 		} else {
 			Rng rng;
 			if (kind == kShade) {
-				// ---------------- SHADE: the top (up to) 64 parked hits
-				const uint32_t n = n_hit < 64u ? n_hit : 64u, base = n_hit - n;
-				active = lane < n;
-				const uint32_t e = active ? base + lane : base;
+				// ---------------- SHADE: the hits held in their lanes, and in the other lanes the top entries of the hit stack (as many as there are: up to 64 in all)
+				const uint32_t n_held = (uint32_t)__popcll(held_mask), n_pop = n_hit < 64u - n_held ? n_hit : 64u - n_held, base = n_hit - n_pop;
+				const unsigned long long free_mask = ~held_mask;
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u)); // free lanes before this one
+				const bool take = !held && rank < n_pop;
+				active = held || take;
 				n_hit = base;
-				const uint32_t cap = q.cap;
-				const uint32_t st = q.hit_w[e], lb = q.hit_w[cap + e];
-				pxw = q.hit_w[2u * cap + e], smp = q.hit_w[3u * cap + e], sector = q.hit_w[4u * cap + e];
-				const V3 frag = mk(q.hit_d[e], q.hit_d[cap + e], q.hit_d[2u * cap + e]);
-				const V3 normal = mk(q.hit_d[3u * cap + e], q.hit_d[4u * cap + e], q.hit_d[5u * cap + e]);
-				T = mk(q.hit_d[6u * cap + e], q.hit_d[7u * cap + e], q.hit_d[8u * cap + e]);
+				constexpr uint32_t cap = kQueuePaths;
+				if (__builtin_expect(n_pop != 0u, 1)) {
+					const uint32_t e = take ? base + rank : base; // (a lane without a hit reads the trip's first entry: sane values that nobody uses)
+					if (!held) {
+						h_st = qld(&q.hit_w[e]), h_lb = qld(&q.hit_w[cap + e]);
+						h_px = qld(&q.hit_w[2u * cap + e]), h_smp = qld(&q.hit_w[3u * cap + e]), h_sector = qld(&q.hit_w[4u * cap + e]);
+						h_frag = mk(qld(&q.hit_d[e]), qld(&q.hit_d[cap + e]), qld(&q.hit_d[2u * cap + e]));
+						h_normal = mk(qld(&q.hit_d[3u * cap + e]), qld(&q.hit_d[4u * cap + e]), qld(&q.hit_d[5u * cap + e]));
+						h_T = mk(qld(&q.hit_d[6u * cap + e]), qld(&q.hit_d[7u * cap + e]), qld(&q.hit_d[8u * cap + e]));
+					}
+				}
+				const uint32_t st = h_st, lb = h_lb;
+				pxw = h_px, smp = h_smp, sector = h_sector;
+				const V3 frag = h_frag, normal = h_normal;
+				T = h_T;
+				RMD_QSTAMP(0u)
 				rng.pixel = (pxw >> 16) * Pt.W + (pxw & 0xFFFFu), rng.sample = smp;
 				rng.block = st >> 16, rng.lobe_bits = lb & 0x3FFFFFu;
 				depth = lb >> 24;
 				const DevObject &o = lobjs[st & 0xFFFFu];
 				// (every lane shades — see render_wave_sorted)
-				shade(Pt, normal, frag, ld3(o.color), o.roughness, o.metalness, cam_pos, rng, ro, rd, T);
+				shade(Pt, normal, frag, ld3(o.color), o.roughness, o.metalness, ld3(Pt.cam_pos), rng, ro, rd, T);
 				depth++;
 				// (see render_wave: a path whose throughput is exactly zero is ended where the caller asked for that)
 				const bool black = Pt.end_black_paths != 0u && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
@@ -1110,11 +1221,13 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 				if (Pt.use_dof) failed = active && !thin_lens_from_pinhole(Pt, ro, rd, rng, ro, rd); // the reference panics there; the sample contributes zero
 			}
 			rng_block = rng.block, lobe_bits = rng.lobe_bits;
+			RMD_QSTAMP(1u)
 			// ---------------- src/trace.rs:239, first part — planes, spheres and the grids' boxes (scene_split.hpp)
 			const bool want = active && !failed;
 			const bool enters = intersect_simple(objs, Pt.n_objects, grids, want, ro, rd, t, oi, Pt.axis_pairs);
 			to_ray = want && enters;
 			classify = want && !enters;
+			RMD_QSTAMP(2u)
 		}
 #if RMD_DIAG
 		if ((Pt.debug_flags & 8u) && Pt.debug_counters) { // trips by kind and the lanes they serve
@@ -1122,24 +1235,31 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			if (lane == 0) atomicAdd(&Pt.debug_counters[10], 1ull), atomicAdd(&Pt.debug_counters[11], (unsigned long long)__popcll(am)), atomicAdd(&Pt.debug_counters[12], kind == kWalk ? (unsigned long long)__popcll(am) : 0ull);
 		}
 #endif
-		// ---------------- the rays that have to walk: pushed onto the ray stack, consecutive entries for the lanes that push
-		if (kind != kWalk) {
+		// ---------------- the rays that have to walk (and the walks that were put aside): pushed onto the ray stack, consecutive entries for the lanes that push
+		// (a WALK trip's lanes have read everything they need of their own entries — by loads that precede these stores in program order)
+		{
 			const unsigned long long pm = __ballot(to_ray);
 			if (pm != 0ull) {
-				const uint32_t cap = q.cap;
+				constexpr uint32_t cap = kQueuePaths;
 				const uint32_t e = n_ray + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
 				if (to_ray) {
-					q.ray_d[e] = ro.x, q.ray_d[cap + e] = ro.y, q.ray_d[2u * cap + e] = ro.z;
-					q.ray_d[3u * cap + e] = rd.x, q.ray_d[4u * cap + e] = rd.y, q.ray_d[5u * cap + e] = rd.z;
-					q.ray_d[6u * cap + e] = T.x, q.ray_d[7u * cap + e] = T.y, q.ray_d[8u * cap + e] = T.z;
-					q.ray_d[9u * cap + e] = t;
-					q.ray_w[e] = (uint32_t)(oi + 1) | (rng_block << 16); // (fewer than 2^16 objects fit the LDS; a lens loop runs at most 4096 rounds)
-					q.ray_w[cap + e] = lobe_bits | (depth << 24);
-					q.ray_w[2u * cap + e] = pxw, q.ray_w[3u * cap + e] = smp, q.ray_w[4u * cap + e] = sector;
+					qst(&q.ray_d[e], ro.x), qst(&q.ray_d[cap + e], ro.y), qst(&q.ray_d[2u * cap + e], ro.z);
+					qst(&q.ray_d[3u * cap + e], rd.x), qst(&q.ray_d[4u * cap + e], rd.y), qst(&q.ray_d[5u * cap + e], rd.z);
+					qst(&q.ray_d[6u * cap + e], T.x), qst(&q.ray_d[7u * cap + e], T.y), qst(&q.ray_d[8u * cap + e], T.z);
+					qst(&q.ray_d[9u * cap + e], t);
+					qst(&q.ray_w[e], (uint32_t)(oi + 1) | (rng_block << 16)); // (fewer than 2^16 objects fit the LDS; a lens loop runs at most 4096 rounds)
+					qst(&q.ray_w[cap + e], lobe_bits | (depth << 24) | (kind == kWalk ? kRayCarried : 0u));
+					qst(&q.ray_w[2u * cap + e], pxw), qst(&q.ray_w[3u * cap + e], smp), qst(&q.ray_w[4u * cap + e], sector);
+					if (kind == kWalk) { // the DDA state grid_intersect_wave has left in this lane's column of the carry
+						qst(&q.ray_d[10u * cap + e], carry->tm[0][lane]), qst(&q.ray_d[11u * cap + e], carry->tm[1][lane]), qst(&q.ray_d[12u * cap + e], carry->tm[2][lane]);
+						qst(&q.ray_w[5u * cap + e], carry->idx[lane]), qst(&q.ray_w[6u * cap + e], carry->prev[lane]);
+						qst(&q.ray_w[7u * cap + e], carry->rem[0][lane]), qst(&q.ray_w[8u * cap + e], carry->rem[1][lane]), qst(&q.ray_w[9u * cap + e], carry->rem[2][lane]);
+					}
 				}
 				n_ray += (uint32_t)__popcll(pm);
 			}
 		}
+		RMD_QSTAMP(4u)
 		// ---------------- classification (the rules of render_wave's phase C)
 		bool terminal = failed, park = false, emitted = false;
 		V3 frag, normal;
@@ -1168,31 +1288,47 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 				}
 			}
 		}
+		RMD_QSTAMP(5u)
 		if (terminal) { // the finished sample: T (.) L into its 32-byte sector of the per-sample buffer (added by sum_kernel, behind the kernel boundary)
 			V3 L = mk(0.0, 0.0, 0.0);
 			if (emitted) L = ld3(lobjs[oi].color); // (fetched here, outside the nest of branches that found the light)
 			L = hadamard(T, L);
 			RMD_GLOBAL double *dst = (RMD_GLOBAL double *)Pt.sample_buf + (size_t)sector * kSampleStride;
+#if RMD_SAMPLE_NT
+			__builtin_nontemporal_store(L.x, dst), __builtin_nontemporal_store(L.y, dst + 1), __builtin_nontemporal_store(L.z, dst + 2); // (written once, read by sum_kernel)
+#else
 			dst[0] = L.x, dst[1] = L.y, dst[2] = L.z;
+#endif
 		}
-		// ---------------- the hits that go on: pushed onto the hit stack
+		// ---------------- the hits that go on: held where they are when the next trip shades them anyway, else pushed onto the hit stack
 		{
 			const unsigned long long pm = __ballot(park);
-			if (pm != 0ull) {
-				const uint32_t cap = q.cap;
+			const uint32_t n_park = (uint32_t)__popcll(pm);
+			const bool hold = RMD_QUEUE_HOLD_HITS && n_park != 0u && n_ray < 64u && n_hit + n_park >= 64u; // = the rule above would select a full SHADE trip next
+			// (unconditional copies: the held values are made here for every lane, so that nothing of them is live across the trip's other phases)
+			h_frag = frag, h_normal = normal, h_T = T;
+			h_st = (uint32_t)oi | (rng_block << 16), h_lb = lobe_bits | (depth << 24), h_px = pxw, h_smp = smp, h_sector = sector;
+			held = hold && park;
+			if (pm != 0ull && !hold) {
+				constexpr uint32_t cap = kQueuePaths;
 				const uint32_t e = n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
 				if (park) {
-					q.hit_d[e] = frag.x, q.hit_d[cap + e] = frag.y, q.hit_d[2u * cap + e] = frag.z;
-					q.hit_d[3u * cap + e] = normal.x, q.hit_d[4u * cap + e] = normal.y, q.hit_d[5u * cap + e] = normal.z;
-					q.hit_d[6u * cap + e] = T.x, q.hit_d[7u * cap + e] = T.y, q.hit_d[8u * cap + e] = T.z;
-					q.hit_w[e] = (uint32_t)oi | (rng_block << 16);
-					q.hit_w[cap + e] = lobe_bits | (depth << 24);
-					q.hit_w[2u * cap + e] = pxw, q.hit_w[3u * cap + e] = smp, q.hit_w[4u * cap + e] = sector;
+					qst(&q.hit_d[e], frag.x), qst(&q.hit_d[cap + e], frag.y), qst(&q.hit_d[2u * cap + e], frag.z);
+					qst(&q.hit_d[3u * cap + e], normal.x), qst(&q.hit_d[4u * cap + e], normal.y), qst(&q.hit_d[5u * cap + e], normal.z);
+					qst(&q.hit_d[6u * cap + e], T.x), qst(&q.hit_d[7u * cap + e], T.y), qst(&q.hit_d[8u * cap + e], T.z);
+					qst(&q.hit_w[e], h_st);
+					qst(&q.hit_w[cap + e], h_lb);
+					qst(&q.hit_w[2u * cap + e], pxw), qst(&q.hit_w[3u * cap + e], smp), qst(&q.hit_w[4u * cap + e], sector);
 				}
-				n_hit += (uint32_t)__popcll(pm);
+				n_hit += n_park;
 			}
 		}
+		RMD_QSTAMP(6u)
+#if RMD_DIAG
+		if (qstamp && lane == 0u) atomicAdd(&Pt.debug_counters[kind * 8u + 7u], 1ull);
+#endif
 	}
+#undef RMD_QSTAMP
 }
 
 // PERSIST = false: one wave per work item, block b's waves take items b * waves .. ; PERSIST = true (tile modes of grid scenes):

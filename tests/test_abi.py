@@ -65,7 +65,7 @@ int main(void) {
   S(rmd_camera); O(rmd_camera, fov_vert); O(rmd_camera, position); O(rmd_camera, focal_length); O(rmd_camera, aperture_radius);
   S(rmd_settings); O(rmd_settings, sample_begin); O(rmd_settings, sample_count); O(rmd_settings, flags); O(rmd_settings, seed);
   S(rmd_tile_rect); O(rmd_tile_rect, height);
-  S(rmd_launch_info); O(rmd_launch_info, split_k); O(rmd_launch_info, persistent); O(rmd_launch_info, end_black_paths); O(rmd_launch_info, has_grid); O(rmd_launch_info, waves_per_workgroup); O(rmd_launch_info, buffered); O(rmd_launch_info, chained);
+  S(rmd_launch_info); O(rmd_launch_info, split_k); O(rmd_launch_info, persistent); O(rmd_launch_info, end_black_paths); O(rmd_launch_info, has_grid); O(rmd_launch_info, waves_per_workgroup); O(rmd_launch_info, buffered); O(rmd_launch_info, chained); O(rmd_launch_info, queued);
   return 0; }
 """
     with tempfile.TemporaryDirectory() as d:
@@ -129,8 +129,8 @@ def test_header_constants_match_the_python_mirror():
 #include <stdio.h>
 #include "raymond_hip.h"
 int main(void) {
-  printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u\n", RMD_ABI_VERSION, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS, RMD_RENDER_END_BLACK_PATHS, (unsigned)RMD_TUNE_SAMPLE_SPLIT, (unsigned)RMD_TUNE_WALK_BATCH,
-         (unsigned)RMD_TUNE_MASK_BUDGET, (unsigned)RMD_TUNE_LAUNCH_FORM, (unsigned)RMD_TUNE_SCRATCH_CAP_MB, (unsigned)RMD_TUNE_WALK_CUT, (unsigned)RMD_TUNE_SPLIT_MIN_SAMPLES, (unsigned)RMD_TUNE_CHAIN_ITEMS, (unsigned)RMD_TUNE_AXIS_PAIRS, (unsigned)RMD_TUNE_COUNT);
+  printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u %u\n", RMD_ABI_VERSION, RMD_RENDER_DOF, RMD_RENDER_TRACE_BLACK_PATHS, RMD_RENDER_END_BLACK_PATHS, (unsigned)RMD_TUNE_SAMPLE_SPLIT, (unsigned)RMD_TUNE_WALK_BATCH,
+         (unsigned)RMD_TUNE_MASK_BUDGET, (unsigned)RMD_TUNE_LAUNCH_FORM, (unsigned)RMD_TUNE_SCRATCH_CAP_MB, (unsigned)RMD_TUNE_WALK_CUT, (unsigned)RMD_TUNE_SPLIT_MIN_SAMPLES, (unsigned)RMD_TUNE_CHAIN_ITEMS, (unsigned)RMD_TUNE_AXIS_PAIRS, (unsigned)RMD_TUNE_PATH_QUEUES, (unsigned)RMD_TUNE_COUNT);
   return 0; }
 """
     with tempfile.TemporaryDirectory() as d:
@@ -139,9 +139,42 @@ int main(void) {
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [abi.RMD_ABI_VERSION, abi.RMD_RENDER_DOF, abi.RMD_RENDER_TRACE_BLACK_PATHS, abi.RMD_RENDER_END_BLACK_PATHS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_WALK_BATCH,
-                   abi.RMD_TUNE_MASK_BUDGET, abi.RMD_TUNE_LAUNCH_FORM, abi.RMD_TUNE_SCRATCH_CAP_MB, abi.RMD_TUNE_WALK_CUT, abi.RMD_TUNE_SPLIT_MIN_SAMPLES, abi.RMD_TUNE_CHAIN_ITEMS, abi.RMD_TUNE_AXIS_PAIRS, 9]
+                   abi.RMD_TUNE_MASK_BUDGET, abi.RMD_TUNE_LAUNCH_FORM, abi.RMD_TUNE_SCRATCH_CAP_MB, abi.RMD_TUNE_WALK_CUT, abi.RMD_TUNE_SPLIT_MIN_SAMPLES, abi.RMD_TUNE_CHAIN_ITEMS, abi.RMD_TUNE_AXIS_PAIRS, abi.RMD_TUNE_PATH_QUEUES, 10]
     cam = scenes.camera(64, 48, aperture_radius=0.5)
     assert Settings(cam, 4).pod().flags == 0
     assert Settings(cam, 4, use_dof=True).pod().flags == abi.RMD_RENDER_DOF
     assert Settings(cam, 4, use_dof=True, trace_black_paths=True).pod().flags == (abi.RMD_RENDER_DOF | abi.RMD_RENDER_TRACE_BLACK_PATHS)
     assert Settings(cam, 4, end_black_paths=True).pod().flags == abi.RMD_RENDER_END_BLACK_PATHS
+
+
+def test_nothing_throws_across_the_boundary_when_the_host_runs_out_of_memory():
+    """include/raymond_hip.h: "nothing throws or aborts across the boundary".  rmd_grid_build_from_mesh keeps a std::vector of std::vectors over every
+    cell; under an address-space limit that leaves no room for them its std::bad_alloc must come back as RMD_ERR_OUT_OF_MEMORY — with a message,
+    with the caller's process alive and able to build a small grid afterwards — and not terminate the caller (a Rust or ctypes host) through an
+    exception that unwinds into C.  Run in a child process: the limit is the child's own."""
+    child = r"""
+import ctypes as C, os, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from raymond_amd import abi, lib
+L = lib.load()
+n = 1_500_000                                     # ~3 n cells, each a std::vector: far more than the limit below leaves
+rng = np.random.default_rng(1)
+base = rng.random((n, 1, 3))
+pos = np.ascontiguousarray((base + 1e-3 * rng.random((n, 3, 3))).reshape(n, 9))
+nrm = np.ascontiguousarray(np.tile(np.array([0.0, 0.0, 1.0] * 3), (n, 1)))
+small_pos, small_nrm = np.ascontiguousarray(pos[:500]), np.ascontiguousarray(nrm[:500])
+vm = int([l for l in open("/proc/self/status") if l.startswith("VmSize")][0].split()[1]) * 1024
+resource.setrlimit(resource.RLIMIT_AS, (vm + (48 << 20), vm + (48 << 20)))
+h = C.c_void_p()
+s = L.rmd_grid_build_from_mesh(pos.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p), n, C.byref(h))
+msg = L.rmd_last_error(None).decode()
+print("status", s, "handle", h.value, "text", msg)
+assert s == abi.RMD_ERR_OUT_OF_MEMORY and not h.value and "memory" in msg
+s2 = L.rmd_grid_build_from_mesh(small_pos.ctypes.data_as(C.c_void_p), small_nrm.ctypes.data_as(C.c_void_p), 500, C.byref(h))
+assert s2 == abi.RMD_OK and h.value
+L.rmd_grid_build_destroy(h)
+print("survived")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

@@ -373,3 +373,67 @@ def test_bench_contract_and_two_rank_rehearsal(gpu_ctx):
     assert d["kernel"]["checksum"] == a["kernel"]["checksum"]
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--assemble", "abi"] + common, capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert bad.returncode != 0  # two ranks on one device: refused loudly, no fallback
+
+
+def _second_gpu_present(ctx):
+    """Through the C-ABI itself: a context on device 1 exists exactly when the box has a second GPU."""
+    h = C.c_void_p()
+    status = ctx.L.rmd_context_create(1, C.byref(h))
+    if status == abi.RMD_OK:
+        ctx.L.rmd_context_destroy(h)
+    return status == abi.RMD_OK
+
+
+def test_two_gpus_over_rccl_by_every_route(gpu_ctx):
+    """The N >= 2 path over the real thing — one rank per GPU, backend nccl = RCCL over xGMI — by all three ways of assembling the frame on
+    rank 0 (gather of owned tiles, reduce of full frames through torch.distributed, reduce through the C-ABI's own rmd_comm_* /
+    rmd_reduce_framebuffer_async): each must give the 1-GPU frame's checksum, and every rank must have seen a world of two on a device of its
+    own.  Then the same through the C++ host mirror with two GPU workers.  Skipped, with the reason printed, on a box with one GPU (every
+    one-GPU rehearsal of these routes runs over gloo or with a world of one: tests above)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if not _second_gpu_present(gpu_ctx):
+        pytest.skip("this box has one GPU: RCCL refuses two ranks on one device, so the N >= 2 routes over nccl cannot run here "
+                    "(rehearsed over gloo in test_bench_contract_and_two_rank_rehearsal; this test runs by itself where rmd_context_create(1) succeeds)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "1", "--spp", "24", "--no-cpu-baseline", "--no-roofline-leg"]
+    env = dict(os.environ)
+    env.pop("RMD_BENCH_BACKEND", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.split("\n") if l.startswith("{")][0])
+    for port, route in ((29581, "gather"), (29582, "reduce"), (29583, "abi")):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--assemble", route] + common,
+                           capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert r.returncode == 0, (route, r.stderr[-3000:])
+        b = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][0])
+        assert b["n_gpus"] == 2 and b["kernel"]["checksum"] == a["kernel"]["checksum"], route
+        assert b["kernel"]["nonfinite_pixels"] == a["kernel"]["nonfinite_pixels"], route
+        ranks = sorted(b["ranks"], key=lambda x: x["rank"])
+        assert [x["rank"] for x in ranks] == [0, 1] and all(x["world_size_seen"] == 2 and x["backend"] == "nccl" for x in ranks), (route, ranks)
+        assert sorted(x["device"] for x in ranks) == [0, 1], (route, ranks)  # one GPU each
+        assert sum(x["samples_per_step"] for x in ranks) == 1920 * 1080 * 24 and all(x["samples_per_step"] > 0 for x in ranks), (route, ranks)
+    # the C++ host mirror (raymond_amd/host: the stand-in for integration/gpu.rs) with one worker per GPU == one rmd_render_tiles call
+    cli = os.path.join(root, "raymond_amd", "host", "raymond_cli")
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        W, H, spp, bounces = 96, 64, 7, 4
+        raw, ppm = os.path.join(d, "o.f64"), os.path.join(d, "o.ppm")
+        env2 = dict(env)
+        env2.pop("RAYMOND_REHEARSE_ON_DEVICE0", None)
+        r = subprocess.run([cli, "render", "dragon:12", str(W), str(H), str(spp), str(bounces), ppm, "--raw", raw, "--spi", "2", "--gpus", "2"],
+                           capture_output=True, text=True, timeout=300, env=env2)
+        assert r.returncode == 0, r.stderr[-2000:]
+        img_cpp = np.fromfile(raw).reshape(H, W, 3)
+    st = Settings(scenes.camera(W, H), sample_count=spp, tile_size=(32, 32), bounce_limit=bounces, seed=scenes.SEED)
+    ds = render.DeviceScene(gpu_ctx, scenes.gold_dragon_standin(n=12))
+    fb = render.Framebuffer(gpu_ctx, W, H)
+    render.render_tiles(gpu_ctx, ds, st.camera_settings, st, generate_tiles(W, H, (32, 32)), fb)
+    assert img_cpp.tobytes() == (fb.download() / float(spp)).tobytes()
+    fb.close(), ds.close()
