@@ -69,6 +69,13 @@ rmd_status rmd_probe_trace_samples(rmd_context *ctx, const rmd_scene *scene, con
  * line passes the centre at more than sqrt(r2a + kb * |centre - origin|^2) is not run through triangle.rs:11-44; tests/test_pretest_allowance.py
  * checks, with the reference's test evaluated in binary64 on adversarial pairs, that no such pair would have passed it. */
 rmd_status rmd_probe_triangle_sphere(size_t n, const double *pos9, double *out5);
+/* The walk's pre-test on explicit (triangle, ray) pairs IN THE DEVICE'S OWN ARITHMETIC — the function the chunk loop calls (grid_walk.hpp:
+ * sphere_pretest, fused multiply-adds included) — beside the device's triangle.rs:11-44 on the same pair.  sphere5 = centre (3), r2a, kb (the caller
+ * chooses the allowance: the triangle's own, or a grid's largest); pass[i] = the pre-test lets the pair through, hit[i] / t[i] = the reference's test.
+ * A pair with hit = 1 and pass = 0 would be a silently missed hit: tests/test_gpu_reference_pins.py asserts there is none among the adversarial
+ * pairs of tests/test_pretest_allowance.py. */
+rmd_status rmd_probe_pretest_pairs(rmd_context *ctx, size_t n, const double *sphere5, const double *pos9, const double *ray6, int32_t *pass,
+                                   int32_t *hit, double *t);
 
 #ifdef __cplusplus
 }

@@ -367,6 +367,20 @@ RMD_DEV void dda_collect_candidates_asm(uint32_t mask_base, uint32_t mask_pad_bi
 	walking = bit == 0u;
 }
 
+// The walk's sphere pre-test (RMD_SPHERE_PREFILTER): does the LINE of the ray (origin pro, direction prd) pass the centre c of a triangle's sphere
+// within sqrt(r2a + kb * |c - pro|^2)?  c, r2a: DevGrid::tri_sph (internal.hpp: triangle_sphere has the error argument); kb: DevGrid::sph_kb, the
+// largest of the grid's triangles'.  This is the one piece of arithmetic on the hot path that is not the reference's: explicit fused multiply-adds
+// (fewer instructions, smaller errors than the allowance assumes).  Precondition: |prd| = 1 to rounding — every ray of the render loop is a
+// normalised vector (generate_primary_ray :332, :266 / :295; the thin lens :359) —: |d|^2 - (d.prd)^2 is the squared distance of the line from c
+// only then (a longer direction would shrink the left-hand side and pass MORE pairs, a shorter one fewer: tests/test_gpu_reference_pins.py feeds
+// the device form the adversarial pairs of tests/test_pretest_allowance.py through rmd_probe_pretest_pairs).  A NaN anywhere: the pair is dropped
+// (the reference's test fails on a NaN too).
+RMD_DEV bool sphere_pretest(V3 c, double r2a, double kb, V3 pro, V3 prd) {
+	const V3 d = c - pro;
+	const double along = __builtin_fma(d.x, prd.x, __builtin_fma(d.y, prd.y, d.z * prd.z)), dd = __builtin_fma(d.x, d.x, __builtin_fma(d.y, d.y, d.z * d.z));
+	return __builtin_fma(-along, along, dd) <= __builtin_fma(kb, dd, r2a);
+}
+
 // Must be called by all 64 lanes of the wave in uniform control flow; `want` selects the lanes that have a ray.
 // lds_mask: occupancy bits of this grid in LDS (bit i covers cells [i << shift, (i+1) << shift)).
 // scr: this wave's scratch in LDS.
@@ -750,10 +764,7 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
 				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
 				if (base + 64u * ahead < total) search(base + 64u * ahead, own_x, tri_x);
-				const V3 d = c - pro;
-				// (the pre-test is not the reference's arithmetic: fused multiply-adds — fewer instructions, smaller errors than the allowance assumes)
-				const double along = __builtin_fma(d.x, prd.x, __builtin_fma(d.y, prd.y, d.z * prd.z)), dd = __builtin_fma(d.x, d.x, __builtin_fma(d.y, d.y, d.z * d.z));
-				const bool pass = w < total && __builtin_fma(-along, along, dd) <= __builtin_fma(sph_kb, dd, r2a); // (a NaN anywhere: dropped — the reference's test fails on a NaN too)
+				const bool pass = w < total && sphere_pretest(c, r2a, sph_kb, pro, prd);
 #if RMD_DIAG
 				if (count_events && (debug_flags & 64u)) { // cross-check: a pair the pre-test drops must fail the reference's test (dbg[16] stays 0)
 					const TriRecord r = load_record(recs + (size_t)tri * kTriRecStride);

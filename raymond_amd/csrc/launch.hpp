@@ -31,6 +31,7 @@ enum ProbeOp {
 	PROBE_FRESNEL_SCHLICK,
 	PROBE_PRIMARY_RAY,
 	PROBE_ELEMENTARY,
+	PROBE_PRETEST_PAIR,
 	PROBE_OP_COUNT
 };
 

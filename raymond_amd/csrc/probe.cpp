@@ -233,6 +233,15 @@ rmd_status rmd_probe_triangle_sphere(size_t n, const double *pos9, double *out5)
 	return RMD_OK;
 }
 
+rmd_status rmd_probe_pretest_pairs(rmd_context *ctx, size_t n, const double *sphere5, const double *pos9, const double *ray6, int32_t *pass, int32_t *hit,
+                                   double *t) {
+	if (n != 0 && (!sphere5 || !pos9 || !ray6 || !pass || !hit || !t)) return rmd::fail(ctx, RMD_ERR_INVALID_ARGUMENT, "probe: bad argument");
+	std::vector<double> out;
+	if (rmd_status s = run_probe(ctx, rmd::PROBE_PRETEST_PAIR, n, {{sphere5, 5}, {pos9, 9}, {ray6, 6}}, 3, out)) return s;
+	for (size_t i = 0; i < n; i++) pass[i] = out[3 * i] != 0.0, hit[i] = out[3 * i + 1] != 0.0, t[i] = out[3 * i + 2];
+	return RMD_OK;
+}
+
 rmd_status rmd_probe_trace_samples(rmd_context *ctx, const rmd_scene *scene, const rmd_camera *cam, const rmd_settings *settings,
                                    size_t n, const uint32_t *xy2, const uint32_t *sample, double *rgb_out, int32_t *path_obj,
                                    uint32_t *path_sub) {

@@ -53,6 +53,15 @@ __global__ __launch_bounds__(64) void probe_kernel(int op, uint32_t n, const dou
 		bool h = triangle_intersect(p0, p1 - p0, p2 - p0, ld3(a + 9), ld3(a + 12), t);
 		o[0] = h, o[1] = h ? t : 0.0;
 	} break;
+	case PROBE_PRETEST_PAIR: {
+		// a = sphere (centre, r2a), kb, triangle positions (9), ray (6): the walk's pre-test in the device's own arithmetic (grid_walk.hpp:
+		// sphere_pretest, the function the chunk loop calls) and the reference's test on the same pair (the record the upload makes: v0, edge1, edge2)
+		V3 p0 = ld3(a + 5), p1 = ld3(a + 8), p2 = ld3(a + 11);
+		const V3 pro = ld3(a + 14), prd = ld3(a + 17);
+		double t = 0.0;
+		const bool h = triangle_intersect(p0, p1 - p0, p2 - p0, pro, prd, t);
+		o[0] = sphere_pretest(ld3(a), a[3], a[4], pro, prd) ? 1.0 : 0.0, o[1] = h, o[2] = h ? t : 0.0;
+	} break;
 	case PROBE_TRIANGLE_NORMAL: {
 		V3 frag = ld3(a + 18) + ld3(a + 21) * a[24];
 		V3 nn = triangle_normal(a, a + 9, a + 25, frag); // sides/area precomputed on the host, as for an uploaded scene

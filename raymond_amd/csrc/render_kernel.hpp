@@ -950,7 +950,8 @@ constexpr uint32_t kQueuedTripBoundPerPath = 2u * RMD_MAX_BOUNCE_LIMIT_DEV + 4u;
 #define RMD_QUEUE_SIDE_ALL 1 // 1: pixel, sample and sector wait in LDS too (44 bytes a lane: 15 waves beside the benchmark mesh's masks) instead of being fetched again behind the walk
 #endif
 constexpr size_t kQueuedSideBytes = 64u * (3u * sizeof(double) + (RMD_QUEUE_SIDE_ALL ? 5u : 2u) * sizeof(uint32_t));
-__host__ __device__ inline size_t queued_wave_lds_bytes() { return sizeof(WalkScratch) + sizeof(WalkCarry) + kQueuedSideBytes + kWaveHeadBytes; }
+constexpr size_t kQueuedDiagBytes = RMD_DIAG ? 24u * sizeof(unsigned long long) : 0u; // DIAG builds: the wave's phase clocks (RMD_DEBUG = 16)
+__host__ __device__ inline size_t queued_wave_lds_bytes() { return sizeof(WalkScratch) + sizeof(WalkCarry) + kQueuedSideBytes + kQueuedDiagBytes + kWaveHeadBytes; }
 
 // Queue traffic is non-temporal (RMD_QUEUE_NT): an entry is written once and read once, the waves' working set is several times the L2, and what it
 // displaces there are the scene's tables, which every walk gathers from (measured with plain accesses: L2 hit rate 73 -> 59 %, mean L1 -> L2 read
@@ -986,6 +987,10 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 	double *side_d = reinterpret_cast<double *>(wave_lds + sizeof(WalkScratch) + sizeof(WalkCarry)) + lane;                             // [0], [64], [128]: throughput
 	uint32_t *side_w = reinterpret_cast<uint32_t *>(wave_lds + sizeof(WalkScratch) + sizeof(WalkCarry) + 192u * sizeof(double)) + lane; // [0], [64]: the entry's first two words
 	if (P.bounce_limit == 0u) return; // (such launches are not made: api.cpp)
+#if RMD_DIAG
+	volatile unsigned long long *qacc = reinterpret_cast<volatile unsigned long long *>(wave_lds + sizeof(WalkScratch) + sizeof(WalkCarry) + kQueuedSideBytes);
+	if (lane < 24u) qacc[lane] = 0ull;
+#endif
 	PathQueues q; // (the capacity is a constant of the build — api.cpp sizes the buffer by the same one — so the four arrays are ONE base address and constant offsets)
 	{
 		constexpr uint32_t cap = kQueuePaths;
@@ -1071,6 +1076,13 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 #endif
 			}
 		}
+		// (no `break` here: the wave that runs into the bound reports, drops every path and pair it holds and leaves through the loop's own exit below —
+		// a second way out of this loop, behind the lane-0 branch of the report, came out of the compiler as a loop that some lanes left and others
+		// did not: the forced-bound test hung)
+		if (RMD_UNLIKELY(trips_left-- == 0ull)) { // (never reached: see below)
+			report_fault(Pt, kFaultQueuedTripLoop, wt);
+			n_hit = 0u, n_ray = 0u, pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu, held = false;
+		}
 		const bool pairs_left = next_item < pool_items; // (false once the launch has no item left: next_item = pool_items = 0xFFFFFFFF)
 		// Which kind of trip.  A FULL trip whenever a stack holds 64 entries — walks first: they are what the other kinds wait for —, else the item's
 		// next 64 pairs, and only when the launch has no pair left to hand out the fuller of the two stacks in a trip that is not full.
@@ -1080,26 +1092,25 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		// non-empty: a trip of max(n_ray, n_hit) >= 1 lanes.  (4) both empty and no pair left: the loop ends.  A WALK trip always serves whatever
 		// rays wait (no ray ever waits for others to join it for ever), and no state selects a trip of a kind whose source is empty — the hang of
 		// round 4's three-list pool (tools/experiments/README.md) was such a state: a generation trip chosen with no free slot.
-		if (RMD_UNLIKELY(trips_left-- == 0ull)) { // (never reached: see above) — the wave reports, drops what it holds and leaves through the loop's own exit
-			report_fault(Pt, kFaultQueuedTripLoop, wt);
-			n_hit = 0u, n_ray = 0u, pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu;
-			break;
-		}
 #if RMD_DIAG
-		// where a wave's time goes, by kind of trip and phase (RMD_DEBUG = 16; every stamp drains the memory counters first: what a phase has
-		// requested is charged to it) — debug_counters[kind * 8 + phase]: 0 = the trip's entries fetched, 1 = shading / ray generation,
-		// 2 = planes, spheres and boxes, 3 = the walk, 4 = ray pushes, 5 = classification, 6 = sample stores and hit pushes, 7 = trips
+		// where a wave's time goes, by kind of trip and phase (RMD_DEBUG = 16) — debug_counters[kind * 8 + phase]: 0 = the trip's entries fetched (until
+		// the first of them is used), 1 = shading / ray generation, 2 = planes, spheres and boxes, 3 = the walk, 4 = ray pushes, 5 = classification,
+		// 6 = sample stores and hit pushes, 7 = trips.  The clock is read where a phase ends, nothing is drained: a phase is charged what it WAITS for,
+		// not what it requests.  Summed per wave in LDS, added to the launch's counters when the wave leaves.
 		const bool qstamp = (Pt.debug_flags & 16u) && Pt.debug_counters;
 		unsigned long long qt_prev = qstamp ? __builtin_amdgcn_s_memtime() : 0ull;
-#define RMD_QSTAMP(phase)                                                                        \
-		if (qstamp) {                                                                                \
-			__builtin_amdgcn_s_waitcnt(0);                                                           \
-			const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
-			if (lane == 0u) atomicAdd(&Pt.debug_counters[kind * 8u + (phase)], now_ - qt_prev);      \
-			qt_prev = __builtin_amdgcn_s_memtime();                                                  \
+#define RMD_QSTAMP(phase)                                                              \
+		if (qstamp) {                                                                      \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+			if (lane == 0u) qacc[kind * 8u + (phase)] += now_ - qt_prev;                   \
+			qt_prev = now_;                                                                \
 		}
+#define RMD_QSTAMP_FETCH                      \
+		if (qstamp) __builtin_amdgcn_s_waitcnt(0); \
+		RMD_QSTAMP(0u) /* (the fetch is charged its own wait) */
 #else
 #define RMD_QSTAMP(phase)
+#define RMD_QSTAMP_FETCH
 #endif
 		uint32_t kind;
 		// (the stacks' counters are wave-uniform by construction; said once per trip, because with the held hits in the loop the compiler's uniformity
@@ -1132,7 +1143,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			t = qld(&q.ray_d[9u * cap + e]);
 			const uint32_t st = qld(&q.ray_w[e]), lb = qld(&q.ray_w[cap + e]);
 			oi = (int)(st & 0xFFFFu) - 1;
-			RMD_QSTAMP(0u)
+			RMD_QSTAMP_FETCH
 			// the rest of the path's state goes from its entry to the lane's column of the side area, and comes back behind the walk
 			side_d[0] = qld(&q.ray_d[6u * cap + e]), side_d[64] = qld(&q.ray_d[7u * cap + e]), side_d[128] = qld(&q.ray_d[8u * cap + e]);
 			side_w[0] = st, side_w[64] = lb;
@@ -1194,7 +1205,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 				pxw = h_px, smp = h_smp, sector = h_sector;
 				const V3 frag = h_frag, normal = h_normal;
 				T = h_T;
-				RMD_QSTAMP(0u)
+				RMD_QSTAMP_FETCH
 				rng.pixel = (pxw >> 16) * Pt.W + (pxw & 0xFFFFu), rng.sample = smp;
 				rng.block = st >> 16, rng.lobe_bits = lb & 0x3FFFFFu;
 				depth = lb >> 24;
@@ -1325,10 +1336,14 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		}
 		RMD_QSTAMP(6u)
 #if RMD_DIAG
-		if (qstamp && lane == 0u) atomicAdd(&Pt.debug_counters[kind * 8u + 7u], 1ull);
+		if (qstamp && lane == 0u) qacc[kind * 8u + 7u] += 1ull;
 #endif
 	}
 #undef RMD_QSTAMP
+#undef RMD_QSTAMP_FETCH
+#if RMD_DIAG
+	if ((P.debug_flags & 16u) && P.debug_counters && lane < 24u) atomicAdd(&P.debug_counters[lane], qacc[lane]);
+#endif
 }
 
 // PERSIST = false: one wave per work item, block b's waves take items b * waves .. ; PERSIST = true (tile modes of grid scenes):

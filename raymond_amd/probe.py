@@ -31,6 +31,7 @@ _SIGS = {
     "rmd_probe_grid_intersect": [_vp, _vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp],
     "rmd_probe_trace_samples": [_vp, _vp, _P(abi.Camera), _P(abi.Settings), _sz, _vp, _vp, _vp, _vp, _vp],
     "rmd_probe_triangle_sphere": [_sz, _vp, _vp],
+    "rmd_probe_pretest_pairs": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 PATH_STRIDE = 17
 _ready = False
@@ -171,3 +172,14 @@ def triangle_sphere(pos9):
     if st != _abi.RMD_OK:
         raise RuntimeError("rmd_probe_triangle_sphere: status %d" % st)
     return out[:, :3], out[:, 3], out[:, 4]
+
+
+def pretest_pairs(ctx, sphere5, pos9, ray6):
+    """The walk's sphere pre-test in the device's own arithmetic and the device's triangle test on explicit pairs -> (passed bool[n], hit bool[n],
+    t float64[n]); sphere5 = centre, r2a, kb per pair.  api: rmd_probe_pretest_pairs."""
+    L = _L()
+    sphere5, pos9, ray6 = _f(sphere5, 5), _f(pos9, 9), _f(ray6, 6)
+    n = pos9.shape[0]
+    passed, hit, t = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n)
+    ctx.check(L.rmd_probe_pretest_pairs(ctx.handle, n, _p(sphere5), _p(pos9), _p(ray6), _p(passed), _p(hit), _p(t)))
+    return passed.astype(bool), hit.astype(bool), t

@@ -5,7 +5,8 @@ failure mode there is a hang: `TaskHandle::await` polls a counter that a panicke
 
 The bounds cannot be reached with the product library, so this test loads the DIAG build of the same sources (`make -C raymond_amd/csrc diag`:
 diag/libraymond_hip.so, built by __graft_entry__.build()) whose RMD_DEBUG bits FORCE each bound: 32 = the trip loops' (stall watch of
-render_wave, trip count of render_wave_sorted), 128 = a persistent wave's work loop.  (A grid walk's round and stepping loops carry no counter of
+render_wave, trip counts of render_wave_sorted and render_wave_queued), 128 = a persistent wave's work loop — the outer one and the draws the
+chained / queued wave bodies make themselves.  (A grid walk's round and stepping loops carry no counter of
 their own: they are bounded by the rays' exit counters — grid_walk.hpp says why.)  One child process, run once.
 
 The same DIAG build also checks the walk's sphere pre-test (bit 64): see the second test."""
@@ -29,9 +30,10 @@ from raymond_amd.scene import Settings, generate_tiles
 assert lib.LIB_PATH.endswith("diag/libraymond_hip.so"), lib.LIB_PATH
 spheres, mesh = scenes.reflective_spheres(), scenes.gold_dragon_standin(n=24)
 
-def attempt(debug, scene, spp, want_words, W=256, H=256):
+def attempt(debug, scene, spp, want_words, W=256, H=256, queues=0, want_queued=None):
     os.environ["RMD_DEBUG"] = str(debug)  # read once, when the context is created (DIAG builds only)
     with render.Context(0) as ctx:
+        ctx.set_tunable(abi.RMD_TUNE_PATH_QUEUES, queues)  # 1: the lane-per-path form of the mesh kernel (render_wave)
         cam = scenes.camera(W, H)
         st = Settings(cam, sample_count=spp, bounce_limit=5, seed=scenes.SEED)
         ds, fb = render.DeviceScene(ctx, scene), render.Framebuffer(ctx, W, H)
@@ -44,6 +46,7 @@ def attempt(debug, scene, spp, want_words, W=256, H=256):
             status, text = e.status, str(e)
         dt = time.perf_counter() - t0
         info = ctx.last_launch_info()
+        assert want_queued is None or info.queued == want_queued, (debug, info.queued)
         if want_words is None:
             assert status == abi.RMD_OK, text
         else:
@@ -72,11 +75,14 @@ def attempt(debug, scene, spp, want_words, W=256, H=256):
 attempt(0, spheres, 128, None)                                   # the DIAG build renders normally without a forced bound
 attempt(32, spheres, 128, ["render_wave_sorted"])                # role-sorted spheres kernel: its trip count
 attempt(32, spheres, 4, ["trip loop of render_wave;"])           # lane-per-path form, direct mode: the stall watch
-attempt(32, mesh, 16, ["trip loop of render_wave;"])             # mesh kernel, split launch
+attempt(32, mesh, 16, ["trip loop of render_wave_queued;"], want_queued=1)          # mesh kernel, split launch: the paths in queues
+attempt(32, mesh, 16, ["trip loop of render_wave;"], queues=1, want_queued=0)       # ... and its lane-per-path form (RMD_TUNE_PATH_QUEUES = 1)
 attempt(32, mesh, 2, ["trip loop of render_wave;"])              # mesh kernel, direct mode
-attempt(128, mesh, 16, ["work loop of a persistent workgroup"], 512, 512)  # a persistent wave's second draw (a launch with several items per wave slot)
+attempt(128, mesh, 16, ["work loop of a persistent workgroup"], 512, 512, want_queued=1)  # a persistent wave's second draw (a launch with several items per wave slot)
+attempt(128, mesh, 16, ["work loop of a persistent workgroup"], 512, 512, queues=1, want_queued=0)
 attempt(128, spheres, 128, ["work loop of a persistent workgroup"], 512, 512)
-attempt(0, mesh, 16, None)
+attempt(0, mesh, 16, None, want_queued=1)
+attempt(0, mesh, 16, None, queues=1, want_queued=0)
 print("faults ok")
 """
 

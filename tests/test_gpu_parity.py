@@ -1134,6 +1134,7 @@ def test_chained_work_items_do_not_change_the_image(gpu_ctx, small_mesh_scene, o
         for name, chain, split, cap in (("chained", 2, 0, 0), ("unchained", 1, 0, 0), ("chained-many-items", 2, 5, 0), ("chained-two-passes", 2, 0, 1), ("direct", 1, 1, 0)):
             gpu_ctx.set_tunable(abi.RMD_TUNE_CHAIN_ITEMS, chain), gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
             gpu_ctx.set_tunable(abi.RMD_TUNE_SCRATCH_CAP_MB, cap), gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, 2)
+            gpu_ctx.set_tunable(abi.RMD_TUNE_PATH_QUEUES, 1)  # the lane-per-path form (the queued form: test_path_queues_do_not_change_the_image)
             try:
                 fb.zero()
                 render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
@@ -1148,13 +1149,70 @@ def test_chained_work_items_do_not_change_the_image(gpu_ctx, small_mesh_scene, o
                 if name == "chained-two-passes" and spp >= 16:
                     assert info.passes >= 2
             finally:
-                for key in (abi.RMD_TUNE_CHAIN_ITEMS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_SCRATCH_CAP_MB, abi.RMD_TUNE_LAUNCH_FORM):
+                for key in (abi.RMD_TUNE_CHAIN_ITEMS, abi.RMD_TUNE_SAMPLE_SPLIT, abi.RMD_TUNE_SCRATCH_CAP_MB, abi.RMD_TUNE_LAUNCH_FORM, abi.RMD_TUNE_PATH_QUEUES):
                     gpu_ctx.set_tunable(key, 0)
         for name, img in frames.items():
             assert same_bits(img, frames["direct"]).all(), (spp, name)
         ref = oracle.OracleScene(small_mesh_scene).render_tiles(st.camera_settings, st, tiles, threads=8)
         assert rel_close(frames["chained"], ref, 1e-9).all(axis=2).mean() >= 0.995
     fb.close(), ds.close()
+
+
+def test_path_queues_do_not_change_the_image(gpu_ctx, small_mesh_scene, oracle):
+    """Persistent split launches of scenes with grids keep their paths in per-wave queues in device memory (render_kernel.hpp: render_wave_queued —
+    ray compaction between bounces: a trip is 64 new samples, 64 parked hits or one grid walk for 64 parked rays; hits are held in their lanes when
+    the next trip shades them anyway; walks that are put aside go back onto the ray stack with their DDA state).  Which lane, trip and wave compute
+    a sample changes nothing: the queued form, the lane-per-path forms and the direct launch give the same frame bit for bit — ragged tiles, thin
+    lens, black paths ended or traced, several passes of the scratch, any split, walks put aside or not, one grid or two — and the oracle's."""
+    from raymond_amd.scene import AccGrid, Grid, Material, Object, Plane, Scene
+
+    two = Scene()  # two grid objects: no walk is put aside there (the carried state is one walk's), every WALK trip walks both grids
+    two.objects.append(Object(Grid(AccGrid.build_from_mesh(scenes.lumpy_sphere_mesh(6, (0.9, 0.9, 0.5), (-0.6, -0.2, 2.6)))), Material.Metal((1.0, 1.0, 0.1), 0.15)))
+    two.objects.append(Object(Plane((0.0, -1.0, 0.0), (0.0, 1.0, 0.0)), Material.Diffuse((0.75, 0.75, 0.75), 0.5)))
+    two.objects.append(Object(Grid(AccGrid.build_from_mesh(scenes.lumpy_sphere_mesh(5, (1.0, 1.1, 0.7), (0.5, 0.0, 2.9)))), Material.Diffuse((0.2, 0.8, 0.3), 0.4)))
+    two.objects.append(Object(Plane((0.0, 2.0, 0.0), (0.0, -1.0, 0.0)), Material.Emission((1.5, 1.5, 1.5))))
+    W, H = 203, 117
+    tiles = generate_tiles(W, H, (32, 32))
+    T = abi
+    keys = (T.RMD_TUNE_PATH_QUEUES, T.RMD_TUNE_SAMPLE_SPLIT, T.RMD_TUNE_SCRATCH_CAP_MB, T.RMD_TUNE_LAUNCH_FORM, T.RMD_TUNE_WALK_CUT, T.RMD_TUNE_CHAIN_ITEMS)
+    for sc, spp, dof, bounces, end_black in ((small_mesh_scene, 12, False, 5, False), (small_mesh_scene, 40, True, 8, False), (small_mesh_scene, 24, False, 5, True),
+                                             (small_mesh_scene, 3, False, 2, False), (two, 16, False, 5, False)):
+        ds = render.DeviceScene(gpu_ctx, sc)
+        fb = render.Framebuffer(gpu_ctx, W, H)
+        st = Settings(scenes.camera(W, H, aperture_radius=0.4 if dof else 0.0), sample_count=spp, bounce_limit=bounces, seed=77, use_dof=dof, end_black_paths=end_black)
+        frames = {}
+        #            name                 queues split cap form cut
+        variants = (("queued",               0,    0,   0,   2,  0),
+                    ("queued-many-items",    0,    5,   0,   2,  0),
+                    ("queued-two-passes",    0,    0,   1,   2,  0),
+                    ("queued-no-walk-cut",   0,    0,   0,   2,  1),
+                    ("queued-cut-of-12",     0,    0,   0,   2, 13),
+                    ("lane-per-path",        1,    0,   0,   2,  0),
+                    ("one-wave-per-item",    0,    3,   0,   1,  0),
+                    ("direct",               1,    1,   0,   0,  0))
+        for name, queues, split, cap, form, cut in variants:
+            for key, val in zip(keys, (queues, split, cap, form, cut, 0)):
+                gpu_ctx.set_tunable(key, val)
+            try:
+                fb.zero()
+                render.render_tiles(gpu_ctx, ds, st.camera_settings, st, tiles, fb)
+                info = gpu_ctx.last_launch_info()
+                frames[name] = fb.download()
+                if name.startswith("queued") and not (name == "queued-many-items" and spp < 8):
+                    assert info.queued == 1 and info.persistent == 1 and info.buffered == 1 and info.chained == 0, (name, spp, info.queued, info.persistent, info.buffered)
+                else:
+                    assert info.queued == 0, name
+                if name == "queued-two-passes" and spp >= 16:
+                    assert info.passes >= 2
+            finally:
+                for key in keys:
+                    gpu_ctx.set_tunable(key, 0)
+        for name, img in frames.items():
+            assert same_bits(img, frames["direct"]).all(), (spp, dof, end_black, name)
+        ref = oracle.OracleScene(sc).render_tiles(st.camera_settings, st, tiles, threads=8)
+        if not end_black:  # (the oracle traces every path: flags 0)
+            assert rel_close(frames["queued"], ref, 1e-9).all(axis=2).mean() >= 0.995
+        fb.close(), ds.close()
 
 
 def test_walk_batching_does_not_change_the_image(gpu_ctx, small_mesh_scene):

@@ -420,3 +420,37 @@ def test_shipped_library_ignores_rmd_debug():
         out = subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout.split()
         digests.add(out[-1])
     assert len(digests) == 1
+
+
+@pytest.mark.parametrize("regime", ["near", "extreme"])
+def test_adversarial_pairs_through_the_device_pre_test(gpu_ctx, regime):
+    """The sphere pre-test of the grid walk is the one piece of arithmetic on the hot path that is not the reference's (grid_walk.hpp: sphere_pretest,
+    three nested fused multiply-adds per side), and a pair it drops wrongly is a silently missed hit.  tests/test_pretest_allowance.py evaluates its
+    formula in numpy, unfused; the DIAG cross-check (tests/test_gpu_faults.py) runs the device form, but on the pairs real renders produce.  Here the
+    adversarial pairs themselves — grazing rays, slivers, far origins, triangles far from the origin — go through the DEVICE's arithmetic
+    (rmd_probe_pretest_pairs: the very function the chunk loop calls) beside the device's triangle.rs:11-44: no pair the device's test accepts may
+    fail the device's pre-test, with the triangle's own allowance kb and with a grid's (the largest kb of the batch: what a scene upload stores).
+    The device's test agrees with the numpy evaluation of the reference's operations hit for hit, and the rays are unit vectors to rounding (the
+    pre-test's precondition)."""
+    from pretest_pairs import adversarial_pairs, dot, moeller_trumbore
+
+    rng = np.random.default_rng(21 if regime == "near" else 22)
+    accepted = 0
+    for _ in range(2):
+        p0, p1, p2, ro, rd, ok = adversarial_pairs(regime, rng, 300_000)
+        assert np.abs(dot(rd, rd)[ok] - 1.0).max() < 1e-14
+        pos9 = np.concatenate([p0, p1, p2], axis=1)
+        rays = np.concatenate([ro, rd], axis=1)
+        centre, r2a, kb = probe.triangle_sphere(pos9)
+        sel = ok & np.isfinite(centre).all(axis=1) & np.isfinite(rays).all(axis=1)
+        pos9, rays, centre, r2a, kb = pos9[sel], rays[sel], centre[sel], r2a[sel], kb[sel]
+        want_hit = moeller_trumbore(p0[sel], (p1 - p0)[sel], (p2 - p0)[sel], ro[sel], rd[sel])
+        for name, k in (("own allowance", kb), ("the batch's largest allowance", np.full_like(kb, kb.max()))):
+            passed, hit, t = probe.pretest_pairs(gpu_ctx, np.concatenate([centre, r2a[:, None], k[:, None]], axis=1), pos9, rays)
+            assert np.array_equal(hit, want_hit), (name, int((hit != want_hit).sum()))  # same operations, same order: the same verdict on every pair
+            dropped = hit & ~passed
+            assert not dropped.any(), (name, int(dropped.sum()), np.flatnonzero(dropped)[:5])
+            assert (t[hit] > 1e-8).all()
+        accepted += int(want_hit.sum())
+        assert passed.mean() < 0.9  # ... and the pre-test does drop pairs here (aimed near the triangle as they are, many graze past its sphere)
+    assert accepted > 10_000

@@ -10,26 +10,7 @@ import numpy as np
 import pytest
 
 
-def _dot(a, b):
-    return (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]  # cgmath: mul_element_wise().sum()
-
-
-def _cross(a, b):
-    return np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], axis=1)
-
-
-def _moeller_trumbore(v0, e1, e2, ro, rd):
-    eps = 0.00000001
-    with np.errstate(all="ignore"):
-        h = _cross(rd, e2)
-        a = _dot(e1, h)
-        f = 1.0 / a
-        s = ro - v0
-        u = f * _dot(s, h)
-        q = _cross(s, e1)
-        v = f * _dot(rd, q)
-        t = f * _dot(e2, q)
-    return ~((a < eps) & (a > -eps)) & ~((u < 0.0) | (u > 1.0)) & ~((v < 0.0) | (u + v > 1.0)) & (t > eps)
+from pretest_pairs import adversarial_pairs, dot as _dot, moeller_trumbore as _moeller_trumbore
 
 
 @pytest.mark.parametrize("regime", ["near", "extreme"])
@@ -40,28 +21,8 @@ def test_no_pair_the_pre_test_drops_passes_the_reference_test(product_lib, regim
     hits = 0
     worst = 0.0
     for _ in range(3):
-        n = 400_000
-        scale = 10.0 ** rng.uniform(-3, 1, n)
-        far = (1, 5) if regime == "extreme" else (-1, 3)
-        p0 = rng.uniform(-5, 5, (n, 3)) * 10.0 ** rng.uniform(far[0], far[1], (n, 1)) + rng.normal(size=(n, 3)) * scale[:, None]
-        p1 = p0 + rng.normal(size=(n, 3)) * scale[:, None]
-        p2 = p0 + rng.normal(size=(n, 3)) * scale[:, None]
-        sliver = rng.uniform(size=n) < 0.3
-        p2 = np.where(sliver[:, None], p0 + (p1 - p0) * rng.uniform(0, 1, (n, 1)) + rng.normal(size=(n, 3)) * (scale * 10.0 ** rng.uniform(-9, -2, n))[:, None], p2)
+        p0, p1, p2, ro, rd, ok = adversarial_pairs(regime, rng, 400_000)
         e1, e2 = p1 - p0, p2 - p0
-        nrm = _cross(e1, e2)
-        nl = np.sqrt(_dot(nrm, nrm))
-        ok = nl > 0
-        # a point in or near the triangle, a direction almost in its plane, an origin far back along it (plus a nudge)
-        target = p0 + e1 * rng.uniform(-0.2, 1.2, (n, 1)) + e2 * rng.uniform(-0.2, 1.2, (n, 1))
-        with np.errstate(all="ignore"):
-            inplane = e1 * rng.normal(size=(n, 1)) + e2 * rng.normal(size=(n, 1))
-            inplane /= np.sqrt(_dot(inplane, inplane))[:, None]
-            tilt = 10.0 ** (rng.uniform(-9.5, -5, n) if regime == "extreme" else rng.uniform(-9, 0, n)) * rng.choice([-1.0, 1.0], n)
-            rd = inplane + (nrm / nl[:, None]) * tilt[:, None]
-            rd /= np.sqrt(_dot(rd, rd))[:, None]
-        dist = 10.0 ** (rng.uniform(1, 6, n) if regime == "extreme" else rng.uniform(-3, 4, n))
-        ro = target - rd * dist[:, None] + rng.normal(size=(n, 3)) * (scale * 10.0 ** rng.uniform(-12, -1, n))[:, None]
         hit = _moeller_trumbore(p0, e1, e2, ro, rd)
         centre, r2a, kb = probe.triangle_sphere(np.concatenate([p0, p1, p2], axis=1))
         d = centre - ro
