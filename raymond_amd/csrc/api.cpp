@@ -772,6 +772,7 @@ static rmd_status render_tiles_async_impl(rmd_context *ctx, const rmd_scene *sce
 		Q.sample_begin = settings->sample_begin + (uint32_t)done;
 		Q.sample_count = settings->sample_count - done < per_pass ? (uint32_t)(settings->sample_count - done) : per_pass;
 		Q.split_k = split > 1u ? choose_split(ctx, scene->n_grids != 0, P.n_work, Q.sample_count) : 1u;
+		Q.sample_magic = Q.sample_count > 1u ? ~0ull / Q.sample_count + 1ull : 0ull; // floor(2^64 / d) + 1 for d >= 2 (2^64 - 1 and 2^64 have the same quotient unless d divides 2^64: then + 1 overshoots by one and is still exact for dividends below 2^32)
 		Q.buffered = buffered ? 1u : 0u;
 		{ // split launches of grid scenes chain their work items (launch.hpp: kChainMaxSamples; RMD_TUNE_CHAIN_ITEMS: 1 = never, 2 = always)
 			const int64_t force = ctx->tunable[RMD_TUNE_CHAIN_ITEMS];

@@ -131,6 +131,8 @@ struct RenderParams {
 	uint32_t queue_paths;               // paths a wave may have in flight (capacity of each of its queues)
 	uint32_t walk_steps_bound;          // most steps a ray's walk can take in any grid of the scene (res.x + res.y + res.z + 3: grid_walk.hpp) — a walk that is put
 	uint32_t _pad3;                     //   aside takes part in one WALK trip per step at worst: part of render_wave_queued's trip bound
+	unsigned long long sample_magic;    // floor(2^64 / sample_count) + 1, or 0 when sample_count is 1: the multiplier by which a queued path gets its sample's
+	                                    //   number back from its scratch sector (render_kernel.hpp: sample_of_sector)
 };
 // Fault words: [0] OR of the kFault* codes, [1] the work item (or list entry) of the wave that reported last, [2] number of reports.
 constexpr uint32_t kFaultTripLoop = 1u;       // render_wave's trip loop (lane-per-path form: direct mode, the mesh kernel, the list probes)

@@ -102,7 +102,7 @@ struct LaunchShape {
 #define RMD_QUEUE_PATHS 256
 #endif
 constexpr uint32_t kQueuePaths = RMD_QUEUE_PATHS;
-inline size_t path_queue_bytes_host(uint32_t cap) { return (size_t)cap * (9u * 8u + 13u * 8u + 5u * 4u + 10u * 4u); } // (render_kernel.hpp: path_queue_bytes)
+inline size_t path_queue_bytes_host(uint32_t cap) { return (size_t)cap * (9u * 8u + 13u * 8u + 4u * 4u + 9u * 4u); } // (render_kernel.hpp: path_queue_bytes)
 static_assert(kQueuePaths >= 192u && kQueuePaths % 64u == 0u, "two stacks short of a full trip + the 64 paths of a generation trip");
 size_t render_lds_bytes(uint32_t n_objects, uint32_t mask_words_total, uint32_t waves_per_wg);
 uint32_t render_waves_per_wg(uint32_t n_objects, uint32_t mask_words_total);

@@ -936,20 +936,28 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 struct PathQueues { // one resident wave's queues: SoA, `cap` entries each (a multiple of 64: every field is 512-byte aligned)
 	RMD_GLOBAL double *hit_d;   // [9][cap]: hit point, surface normal, throughput
 	RMD_GLOBAL double *ray_d;   // [13][cap]: origin, direction, throughput, distance of the closest plane / sphere hit so far (kFMax: none); t_max of a walk put aside
-	RMD_GLOBAL uint32_t *hit_w; // [5][cap]: object | next RNG block << 16; lobe bits | depth << 24; x | y << 16; sample; scratch sector
-	RMD_GLOBAL uint32_t *ray_w; // [10][cap]: (closest plane / sphere + 1, 0 = none) | next RNG block << 16; then as above, kRayCarried in the second word:
+	RMD_GLOBAL uint32_t *hit_w; // [4][cap]: object | next RNG block << 16; lobe bits | depth << 24; x | y << 16; scratch sector (the sample's number is
+	                            //   a function of its sector: sample_of_sector)
+	RMD_GLOBAL uint32_t *ray_w; // [9][cap]: (closest plane / sphere + 1, 0 = none) | next RNG block << 16; then as above, kRayCarried in the second word:
 	uint32_t cap;               //   the ray's walk was put aside (grid_walk.hpp: WalkCarry) and its cell index, previous cell and exit counters follow
 };
 constexpr uint32_t kRayCarried = 1u << 23; // (the lobe bits are 22, the depth sits in the top byte)
-__host__ __device__ inline size_t path_queue_bytes(uint32_t cap) { return (size_t)cap * (9u * 8u + 13u * 8u + 5u * 4u + 10u * 4u); }
+__host__ __device__ inline size_t path_queue_bytes(uint32_t cap) { return (size_t)cap * (9u * 8u + 13u * 8u + 4u * 4u + 9u * 4u); }
+// The sample a scratch sector belongs to.  sector = (wave tile * sample_count + s) * 64 + pixel slot with s < sample_count the sample's number within
+// the pass (render_wave_queued: GEN), so s = (sector >> 6) mod sample_count: by the host's multiplier M = floor(2^64 / sample_count) + 1
+// (RenderParams::sample_magic; exact for every 32-bit dividend: a * sample_count < 2^64), 0 for a pass of ONE sample, where s = 0.
+RMD_DEV uint32_t sample_of_sector(const RenderParams &P, uint32_t sector) {
+	const uint32_t a = sector >> 6, q = (uint32_t)__umul64hi((unsigned long long)a, P.sample_magic);
+	return P.sample_begin + (P.sample_magic != 0ull ? a - q * P.sample_count : 0u);
+}
 constexpr uint32_t kQueuedTripBoundPerPath = 2u * RMD_MAX_BOUNCE_LIMIT_DEV + 4u; // trips per path, as if ONE lane ran them all: a segment is at most a SHADE and a WALK trip
 // LDS of a wave of the queued form: the walk scratch, the walk's carry area (grid_walk.hpp: WalkCarry — during a call the ring of its pre-test; around a
 // call the DDA states of the walks it takes up / puts aside, on their way from / to the ray stack), per lane what a walking path does not need
 // during its walk (throughput, RNG state: 32 bytes a lane), then the head — 7,184 bytes: 16 waves beside the benchmark mesh's 36.7 KB of masks
 #ifndef RMD_QUEUE_SIDE_ALL
-#define RMD_QUEUE_SIDE_ALL 1 // 1: pixel, sample and sector wait in LDS too (44 bytes a lane: 15 waves beside the benchmark mesh's masks) instead of being fetched again behind the walk
+#define RMD_QUEUE_SIDE_ALL 1 // 1: pixel and sector wait in LDS too (40 bytes a lane: 7,696 bytes a wave, 16 waves beside the benchmark mesh's masks) instead of being fetched again behind the walk
 #endif
-constexpr size_t kQueuedSideBytes = 64u * (3u * sizeof(double) + (RMD_QUEUE_SIDE_ALL ? 5u : 2u) * sizeof(uint32_t));
+constexpr size_t kQueuedSideBytes = 64u * (3u * sizeof(double) + (RMD_QUEUE_SIDE_ALL ? 4u : 2u) * sizeof(uint32_t));
 constexpr size_t kQueuedDiagBytes = RMD_DIAG ? 24u * sizeof(unsigned long long) : 0u; // DIAG builds: the wave's phase clocks (RMD_DEBUG = 16)
 __host__ __device__ inline size_t queued_wave_lds_bytes() { return sizeof(WalkScratch) + sizeof(WalkCarry) + kQueuedSideBytes + kQueuedDiagBytes + kWaveHeadBytes; }
 
@@ -1000,7 +1008,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		q.hit_d = (RMD_GLOBAL double *)base;
 		q.ray_d = q.hit_d + (size_t)9u * cap;
 		q.hit_w = (RMD_GLOBAL uint32_t *)(q.ray_d + (size_t)13u * cap);
-		q.ray_w = q.hit_w + (size_t)5u * cap;
+		q.ray_w = q.hit_w + (size_t)4u * cap;
 	}
 	enum { kGen = 0, kShade = 1, kWalk = 2 };
 
@@ -1040,7 +1048,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 	bool held = false;
 	V3 h_frag, h_normal, h_T;
 	RMD_UNDEF3(h_frag) RMD_UNDEF3(h_normal) RMD_UNDEF3(h_T)
-	uint32_t h_st = 0, h_lb = 0, h_px = 0, h_smp = 0, h_sector = 0;
+	uint32_t h_st = 0, h_lb = 0, h_px = 0, h_sector = 0;
 	for (;;) {
 		// the launch parameters a trip needs, re-read from the kernel arguments (see render_wave)
 		KernargWords src = kernarg_params;
@@ -1126,7 +1134,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		else break;
 
 		bool active, failed = false, classify, to_ray = false;
-		uint32_t depth = 1, lobe_bits = 0, rng_block = 0, pxw = 0, smp = 0, sector = 0, sub = 0;
+		uint32_t depth = 1, lobe_bits = 0, rng_block = 0, pxw = 0, sector = 0, sub = 0;
 		int oi = -1;
 		double t;
 		V3 ro, rd, T;
@@ -1148,7 +1156,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			side_d[0] = qld(&q.ray_d[6u * cap + e]), side_d[64] = qld(&q.ray_d[7u * cap + e]), side_d[128] = qld(&q.ray_d[8u * cap + e]);
 			side_w[0] = st, side_w[64] = lb;
 #if RMD_QUEUE_SIDE_ALL
-			side_w[128] = qld(&q.ray_w[2u * cap + e]), side_w[192] = qld(&q.ray_w[3u * cap + e]), side_w[256] = qld(&q.ray_w[4u * cap + e]);
+			side_w[128] = qld(&q.ray_w[2u * cap + e]), side_w[192] = qld(&q.ray_w[3u * cap + e]);
 #endif
 			// Walks put aside (grid_walk.hpp: cut_lanes): a call with many walkers stops stepping under its last K rays and ends under its last 2K
 			// walkers; what is left of such a walk — its DDA state — goes back onto the ray stack with the ray (kRayCarried) and the walk goes on in
@@ -1158,8 +1166,8 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			if (__ballot(carried) != 0ull) {
 				if (carried) {
 					carry->tm[0][lane] = qld(&q.ray_d[10u * cap + e]), carry->tm[1][lane] = qld(&q.ray_d[11u * cap + e]), carry->tm[2][lane] = qld(&q.ray_d[12u * cap + e]);
-					carry->idx[lane] = qld(&q.ray_w[5u * cap + e]), carry->prev[lane] = qld(&q.ray_w[6u * cap + e]);
-					carry->rem[0][lane] = qld(&q.ray_w[7u * cap + e]), carry->rem[1][lane] = qld(&q.ray_w[8u * cap + e]), carry->rem[2][lane] = qld(&q.ray_w[9u * cap + e]);
+					carry->idx[lane] = qld(&q.ray_w[4u * cap + e]), carry->prev[lane] = qld(&q.ray_w[5u * cap + e]);
+					carry->rem[0][lane] = qld(&q.ray_w[6u * cap + e]), carry->rem[1][lane] = qld(&q.ray_w[7u * cap + e]), carry->rem[2][lane] = qld(&q.ray_w[8u * cap + e]);
 				}
 			}
 			const bool cut = n >= kWalkCutMinWalkers; // (every walker of such a call takes at least one step: walks always finish)
@@ -1173,10 +1181,10 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			// (pixel, sample and sector are not needed before the trip's stores: fetched from the entry here — it stays as it is until this trip's own pushes —
 			// with the classification to arrive under)
 #if RMD_QUEUE_SIDE_ALL
-			pxw = side_w[128], smp = side_w[192], sector = side_w[256];
+			pxw = side_w[128], sector = side_w[192];
 #else
 			const uint32_t e2 = n_ray + (active ? lane : 0u); // (= e, made again: one register fewer across the walk)
-			pxw = qld(&q.ray_w[2u * cap + e2]), smp = qld(&q.ray_w[3u * cap + e2]), sector = qld(&q.ray_w[4u * cap + e2]);
+			pxw = qld(&q.ray_w[2u * cap + e2]), sector = qld(&q.ray_w[3u * cap + e2]);
 #endif
 			to_ray = carried; // an unfinished walk: back onto the stack (its closest plane / sphere hit is unchanged: a walk that has found nothing yet merges nothing)
 			classify = active && !carried;
@@ -1195,18 +1203,18 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 					const uint32_t e = take ? base + rank : base; // (a lane without a hit reads the trip's first entry: sane values that nobody uses)
 					if (!held) {
 						h_st = qld(&q.hit_w[e]), h_lb = qld(&q.hit_w[cap + e]);
-						h_px = qld(&q.hit_w[2u * cap + e]), h_smp = qld(&q.hit_w[3u * cap + e]), h_sector = qld(&q.hit_w[4u * cap + e]);
+						h_px = qld(&q.hit_w[2u * cap + e]), h_sector = qld(&q.hit_w[3u * cap + e]);
 						h_frag = mk(qld(&q.hit_d[e]), qld(&q.hit_d[cap + e]), qld(&q.hit_d[2u * cap + e]));
 						h_normal = mk(qld(&q.hit_d[3u * cap + e]), qld(&q.hit_d[4u * cap + e]), qld(&q.hit_d[5u * cap + e]));
 						h_T = mk(qld(&q.hit_d[6u * cap + e]), qld(&q.hit_d[7u * cap + e]), qld(&q.hit_d[8u * cap + e]));
 					}
 				}
 				const uint32_t st = h_st, lb = h_lb;
-				pxw = h_px, smp = h_smp, sector = h_sector;
+				pxw = h_px, sector = h_sector;
 				const V3 frag = h_frag, normal = h_normal;
 				T = h_T;
 				RMD_QSTAMP_FETCH
-				rng.pixel = (pxw >> 16) * Pt.W + (pxw & 0xFFFFu), rng.sample = smp;
+				rng.pixel = (pxw >> 16) * Pt.W + (pxw & 0xFFFFu), rng.sample = sample_of_sector(Pt, sector);
 				rng.block = st >> 16, rng.lobe_bits = lb & 0x3FFFFFu;
 				depth = lb >> 24;
 				const DevObject &o = lobjs[st & 0xFFFFu];
@@ -1222,9 +1230,9 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 				next_item += 64u;
 				active = k < pool_items && (k & 7u) < tile.w && ((k >> 3) & 7u) < tile.h;
 				const uint32_t x = tile.x0 + (k & 7u), y = tile.y0 + ((k >> 3) & 7u);
-				pxw = x | y << 16, smp = Pt.sample_begin + pool_first + (k >> 6);
+				pxw = x | y << 16;
 				sector = (wt * Pt.sample_count + pool_first + (k >> 6)) * 64u + (k & 63u); // (< 2^32: api.cpp caps a pass)
-				rng.pixel = y * Pt.W + x, rng.sample = smp, rng.block = 0u, rng.lobe_bits = 0u;
+				rng.pixel = y * Pt.W + x, rng.sample = Pt.sample_begin + pool_first + (k >> 6), rng.block = 0u, rng.lobe_bits = 0u;
 				T = mk(1.0, 1.0, 1.0);
 				double u0, u1;
 				rng.next2(Pt.key0, Pt.key1, u0, u1); // block 0: the pixel jitter (:326-327)
@@ -1260,11 +1268,11 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 					qst(&q.ray_d[9u * cap + e], t);
 					qst(&q.ray_w[e], (uint32_t)(oi + 1) | (rng_block << 16)); // (fewer than 2^16 objects fit the LDS; a lens loop runs at most 4096 rounds)
 					qst(&q.ray_w[cap + e], lobe_bits | (depth << 24) | (kind == kWalk ? kRayCarried : 0u));
-					qst(&q.ray_w[2u * cap + e], pxw), qst(&q.ray_w[3u * cap + e], smp), qst(&q.ray_w[4u * cap + e], sector);
+					qst(&q.ray_w[2u * cap + e], pxw), qst(&q.ray_w[3u * cap + e], sector);
 					if (kind == kWalk) { // the DDA state grid_intersect_wave has left in this lane's column of the carry
 						qst(&q.ray_d[10u * cap + e], carry->tm[0][lane]), qst(&q.ray_d[11u * cap + e], carry->tm[1][lane]), qst(&q.ray_d[12u * cap + e], carry->tm[2][lane]);
-						qst(&q.ray_w[5u * cap + e], carry->idx[lane]), qst(&q.ray_w[6u * cap + e], carry->prev[lane]);
-						qst(&q.ray_w[7u * cap + e], carry->rem[0][lane]), qst(&q.ray_w[8u * cap + e], carry->rem[1][lane]), qst(&q.ray_w[9u * cap + e], carry->rem[2][lane]);
+						qst(&q.ray_w[4u * cap + e], carry->idx[lane]), qst(&q.ray_w[5u * cap + e], carry->prev[lane]);
+						qst(&q.ray_w[6u * cap + e], carry->rem[0][lane]), qst(&q.ray_w[7u * cap + e], carry->rem[1][lane]), qst(&q.ray_w[8u * cap + e], carry->rem[2][lane]);
 					}
 				}
 				n_ray += (uint32_t)__popcll(pm);
@@ -1318,7 +1326,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			const bool hold = RMD_QUEUE_HOLD_HITS && n_park != 0u && n_ray < 64u && n_hit + n_park >= 64u; // = the rule above would select a full SHADE trip next
 			// (unconditional copies: the held values are made here for every lane, so that nothing of them is live across the trip's other phases)
 			h_frag = frag, h_normal = normal, h_T = T;
-			h_st = (uint32_t)oi | (rng_block << 16), h_lb = lobe_bits | (depth << 24), h_px = pxw, h_smp = smp, h_sector = sector;
+			h_st = (uint32_t)oi | (rng_block << 16), h_lb = lobe_bits | (depth << 24), h_px = pxw, h_sector = sector;
 			held = hold && park;
 			if (pm != 0ull && !hold) {
 				constexpr uint32_t cap = kQueuePaths;
@@ -1329,7 +1337,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 					qst(&q.hit_d[6u * cap + e], T.x), qst(&q.hit_d[7u * cap + e], T.y), qst(&q.hit_d[8u * cap + e], T.z);
 					qst(&q.hit_w[e], h_st);
 					qst(&q.hit_w[cap + e], h_lb);
-					qst(&q.hit_w[2u * cap + e], pxw), qst(&q.hit_w[3u * cap + e], smp), qst(&q.hit_w[4u * cap + e], sector);
+					qst(&q.hit_w[2u * cap + e], pxw), qst(&q.hit_w[3u * cap + e], sector);
 				}
 				n_hit += n_park;
 			}
