@@ -80,6 +80,42 @@ def algorithmic_bytes_per_sample(name, spp, counters, all_cells=False, work_done
     return 8.0 * cells / n + 76.0 * tests / n + 72.0 * c["mesh_hits"] / n + 24.0 / spp
 
 
+def load_kernel_counters():
+    """What the mesh kernel itself counts per sample (tools/kernel_counters.py: DIAG build, RMD_DEBUG = 8), committed fixture."""
+    path = os.path.join(ROOT, "tests", "golden", "kernel_counters.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
+def requested_bytes_per_sample(name, spp, counters, kernel_counters):
+    """The bytes the kernel REQUESTS per sample, by its own counts: per (ray, triangle) pair its rounds number a 4-byte index and a 32-byte sphere; per
+    pair that passes the pre-test a 72-byte record; per visited cell that holds a triangle an 8-byte entry; per shaded mesh hit 176 bytes (positions,
+    normals, Heron constants); per path through a queue its entry written and read (ray 96 B, hit 88 B each way); per sample a 24-byte store and, once,
+    the sum's 24-byte load; the pixel once per launch.  (SURVEY.md section 8d's formula prices the REFERENCE's work instead: `achieved` / `frac`.)"""
+    k, c = kernel_counters.get(name), counters.get(name)
+    if not k or not c:
+        return None
+    n = float(c["samples"])
+    return (36.0 * k["pairs_numbered_per_sample"] + 72.0 * k["pairs_passing_the_pre_test_per_sample"] + 8.0 * c.get("occupied_cells", c["cells"]) / n
+            + 176.0 * c["mesh_hits"] / n + 2.0 * 96.0 * k["rays_pushed_per_sample"] + 2.0 * 88.0 * k["hits_pushed_per_sample"] + 48.0 + 48.0 / spp)
+
+
+def gpu_state():
+    """Clocks and power of GPU 0 as rocm-smi reports them NOW (the box-to-box spread of a VALU-bound kernel has to have a cause beside it)."""
+    import subprocess
+
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        card = d[sorted(d)[0]]
+        keep = {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "fclk", "socclk", "power", "performance level"))}
+        return keep or {"raw": r.stdout[:400]}
+    except Exception as e:  # (no rocm-smi, no permission: say so instead of failing the bench)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def usable_cpus():
     """Threads worth starting: the affinity mask, capped by the cgroup CPU quota when there is one (a container may list
     256 CPUs but be granted 16 cores' worth of time; more runnable threads than that only add contention)."""
@@ -367,6 +403,7 @@ def main():
 
     name = args.workload
     spp = args.spp if args.spp is not None else scenes.CONFIGS[name][3]
+    gpu_before = gpu_state() if rank == 0 else None
     main_run = run_workload(name, spp, args.steps, args.warmup, reduce=True)
     ms_per_step = main_run["elapsed"] / args.steps * 1e3
     value = main_run["samples_per_step"] * args.steps / main_run["elapsed"] / 1e6
@@ -396,6 +433,8 @@ def main():
         },
     }
 
+    if rank == 0:
+        out["gpu"] = {"before_the_timed_steps": gpu_before, "after_the_timed_steps": gpu_state()}
     # who took part (N > 1): every rank's own view — its rank, the world size IT saw, its device and the samples of its tile share — gathered to rank 0
     if dist is not None:
         mine = {"rank": rank, "world_size_seen": int(dist.get_world_size()), "device": int(local_rank), "backend": backend,
@@ -423,7 +462,7 @@ def main():
         ach = bps * main_run["my_samples"] / (avg_ms * 1e-3) / 1e9
         # <MODE, GRID> as rocprofv3 prints it: launches split every tile's samples over several waves (MODE 1) + the ordered sum
         # mesh scenes: persistent render kernel + sum_kernel; spheres: the render kernel's waves add the samples themselves
-        kname = ("rmd::render_kernel<1, true, true, true> + rmd::sum_kernel" if scenes.CONFIGS[name][0] != "reflective_spheres"
+        kname = ("rmd::render_kernel<1, true, true, false, true> + rmd::sum_kernel" if scenes.CONFIGS[name][0] != "reflective_spheres"
                  else "rmd::render_kernel<1, false, true> (persistent workgroups, ordered sample sum inside)")
         out["kernel"] = {"name": kname, "avg_ms": round(avg_ms, 3), "launches": len(main_run["kernel_ms"]), "checksum": main_run["checksum"],
                          "nonfinite_pixels": main_run["nonfinite_pixels"]}
@@ -466,6 +505,12 @@ def main():
                 "frac_with_every_visited_cell_at_8_bytes": algorithmic_bytes_per_sample(counter_key, rspp, counters, all_cells=True) * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "checksum": rr["checksum"], "nonfinite_pixels": rr["nonfinite_pixels"],
             }
+            req = requested_bytes_per_sample(counter_key, rspp, counters, load_kernel_counters())
+            if req is not None:
+                # what the kernel asks the memory system for, by its own counters (tests/golden/kernel_counters.json)
+                leg["bytes_requested"] = {"per_sample": round(req, 2), "per_launch": req * rr["samples_per_step"],
+                                          "gbs": round(req * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9, 2),
+                                          "frac": req * rr["samples_per_step"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             done = algorithmic_bytes_per_sample(counter_key, rspp, counters, work_done=True)
             if done is not None:
                 # the contractual `frac` prices the REFERENCE's triangle tests; this one prices the tests the kernel runs (22 % fewer)
@@ -481,20 +526,22 @@ def main():
                 leg["valu"] = v
                 leg["valu_issue_frac"], leg["useful_frac"] = v["valu_issue_frac"], v["useful_frac"]
                 leg["bound"], leg["bound_by_counters"] = bound_by_counters(leg)
-            return leg
+            # the roof that binds first: bound, the vector ALUs' issue and useful fractions — then the contractual HBM figures
+            first = ("bound", "bound_by_counters", "valu_issue_frac", "useful_frac")
+            return {**{k: leg[k] for k in first if k in leg}, **{k: v for k, v in leg.items() if k not in first}}
 
         rl = mesh_leg("default", args.roofline_steps, "C3_reference", "C3")
         rl.update({
             "workload": "C3: gold_dragon_standin (99,372 triangles, DDA grid), 1920x1080, %d spp, 5 bounces, one launch; rmd_settings.flags 0 = "
                         "reference-identical: every path traced to its end" % rspp,
-            "kernel": "rmd::render_kernel<1, true, true, true> + rmd::sum_kernel",
+            "kernel": "rmd::render_kernel<1, true, true, false, true> + rmd::sum_kernel (persistent workgroups; the paths in per-wave queues in device memory: render_wave_queued)",
             "definition": "achieved / frac = ALGORITHMIC bytes per launch / launch time — most of these bytes are answered by LDS (occupancy mask), L2 and the "
                           "Infinity Cache, so the figure saturates and does not rank kernels any more; measured_gbs / measured_frac = L2<->fabric bytes by PMC, "
                           "an upper bound on HBM bytes; valu_issue_frac = 1.667 ns / (ns per wave-level vector instruction per SIMD): the bound that binds; "
                           "useful_frac = valu_issue_frac x lane utilisation",
             "how": "achieved = algorithmic bytes per launch (8 B x visited cells that hold a triangle + 76 B x triangle tests + 72 B x shaded mesh hits per sample, "
                    "oracle counters in tests/golden/work_counters.json: C3_reference for flags 0, C3 for ending_black_paths, + 24 B/pixel) / mean launch duration "
-                   "from HIP events on the launch stream; profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true, true> (persistent workgroups, chained work items) + "
+                   "from HIP events on the launch stream; profiles/: the rocprofv3 kernel-trace mean of render_kernel<1, true, true, false, true> (persistent workgroups, path queues) + "
                    "sum_kernel over the same launches; valu / traffic: committed rocprofv3 --pmc passes (separate SQ / FETCH_SIZE / WRITE_SIZE passes), "
                    "\"stale\": true when the sources have changed since",
         })

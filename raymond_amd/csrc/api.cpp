@@ -712,8 +712,8 @@ static rmd_status render_tiles_async_impl(rmd_context *ctx, const rmd_scene *sce
 	rmd::RenderParams P = rmd::make_params(ctx, scene, camera, settings);
 	P.n_work = ctx->n_wave_tiles;
 	if (P.debug_flags & 24u) {
-		if (!ctx->d_debug_counters) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_debug_counters, 24 * sizeof(unsigned long long)));
-		RMD_HIP(ctx, hipMemsetAsync(ctx->d_debug_counters, 0, 24 * sizeof(unsigned long long), ctx->stream));
+		if (!ctx->d_debug_counters) RMD_HIP(ctx, hipMalloc((void **)&ctx->d_debug_counters, 40 * sizeof(unsigned long long)));
+		RMD_HIP(ctx, hipMemsetAsync(ctx->d_debug_counters, 0, 40 * sizeof(unsigned long long), ctx->stream));
 		P.debug_counters = ctx->d_debug_counters;
 	}
 	bool buffered = false;
@@ -831,7 +831,7 @@ static rmd_status render_tiles_async_impl(rmd_context *ctx, const rmd_scene *sce
 	RMD_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
 	ctx->timed = true;
 	if (P.debug_flags & 24u) {
-		unsigned long long h[24];
+		unsigned long long h[40];
 		RMD_HIP(ctx, hipMemcpyAsync(h, ctx->d_debug_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
 		RMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		if ((P.debug_flags & 16u) && ctx->last_launch.queued) {
@@ -839,6 +839,8 @@ static rmd_status render_tiles_async_impl(rmd_context *ctx, const rmd_scene *sce
 			for (int k = 0; k < 3; k++)
 				std::fprintf(stderr, "[rmd queued stamps, cycles] %s trips=%llu fetch=%llu make_ray=%llu simple=%llu walk=%llu ray_push=%llu classify=%llu stores=%llu\n", kinds[k], h[k * 8 + 7],
 				             h[k * 8 + 0], h[k * 8 + 1], h[k * 8 + 2], h[k * 8 + 3], h[k * 8 + 4], h[k * 8 + 5], h[k * 8 + 6]);
+			std::fprintf(stderr, "[rmd queued stamps, cycles] inside the walks: init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
+			             h[24], h[25], h[26], h[27], h[29], h[30], h[31]);
 		} else if (P.debug_flags & 16u)
 			std::fprintf(stderr, "[rmd stamps, cycles] wave_total=%llu next_ray=%llu simple=%llu walk=%llu classify=%llu | walk: init=%llu stepping=%llu entry_wait=%llu scan=%llu (chunk search+load+test)=%llu hits=%llu tail=%llu\n",
 			             h[0], h[1], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[13], h[14], h[15]);
@@ -847,6 +849,8 @@ static rmd_status render_tiles_async_impl(rmd_context *ctx, const rmd_scene *sce
 			             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[7], h[13], h[14], h[15]);
 		if ((P.debug_flags & 16u) == 0u)
 			std::fprintf(stderr, "[rmd debug] sphere pre-test: pairs passed=%llu full chunks=%llu | pairs dropped that pass the reference's test (flag 64; must be 0)=%llu\n", h[17], h[18], h[16]);
+		if ((P.debug_flags & 16u) == 0u && ctx->last_launch.queued)
+			std::fprintf(stderr, "[rmd debug] path queues: rays pushed=%llu (of them walks put aside=%llu) rays held in their lanes=%llu hits pushed=%llu hits held in their lanes=%llu\n", h[19], h[22], h[23], h[20], h[21]);
 	}
 	return RMD_OK;
 }

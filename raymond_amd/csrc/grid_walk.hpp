@@ -780,16 +780,69 @@ RMD_DEV void grid_intersect_wave(const DevGrid &g, const uint32_t *lds_mask, Wal
 				if (count_events && lane == 0) atomicAdd(&dbg[17], (unsigned long long)__popcll(pm));
 				if (ring_tail - ring_head >= 64u) full();
 			};
+			// RMD_SPHERE_AHEAD: the same with the NEXT chunk's spheres requested while this chunk is tested.  The chunk loop is what a walk's time is
+			// (DIAG phase clocks of render_wave_queued: the chunks are ~85 % of a walk call, the walks ~60 % of the kernel) and what it waits for is the
+			// 32-byte gather of each pair's sphere — scattered over 3.2 MB, behind an L2 that the scene's tables overflow.  pretest() requests a
+			// chunk's spheres where it needs them (under the ray fetch and the search of the chunk after next: half a chunk of cover); here the
+			// search comes first, then the request for the spheres of the chunk that is tested NEXT (its triangle indices were requested a chunk
+			// ago), then this chunk's tests on the spheres the previous chunk requested: a whole chunk of cover for 8 more live registers.
+			struct Sph {
+				V3 c;
+				double r2a;
+			};
+			[[maybe_unused]] auto load_sph = [&](uint32_t tri) {
+				const RMD_GLOBAL double *sp = spheres + (size_t)tri * 4u;
+				Sph sph;
+				sph.c = ld3(sp), sph.r2a = sp[3];
+				return sph;
+			};
+			[[maybe_unused]] auto pretest_ahead = [&](uint32_t base, uint32_t &own_x, uint32_t &tri_x, const Sph &cur, const uint32_t &tri_next, Sph &next, bool have_next) {
+				const uint32_t w = base + lane;
+				const uint32_t tri = tri_x, own_now = own_x;
+				if (base + 64u * ahead < total) search(base + 64u * ahead, own_x, tri_x);
+				if (have_next) next = load_sph(tri_next);
+				const int src = (int)((own_now & 63u) << 2);
+				const V3 pro = mk(bperm_f64(src, ro.x), bperm_f64(src, ro.y), bperm_f64(src, ro.z));
+				const V3 prd = mk(bperm_f64(src, rd.x), bperm_f64(src, rd.y), bperm_f64(src, rd.z));
+				const bool pass = w < total && sphere_pretest(cur.c, cur.r2a, sph_kb, pro, prd);
+#if RMD_DIAG
+				if (count_events && (debug_flags & 64u)) { // cross-check: a pair the pre-test drops must fail the reference's test (dbg[16] stays 0)
+					const TriRecord r = load_record(recs + (size_t)tri * kTriRecStride);
+					double tt;
+					const bool hh = triangle_intersect(r.v0, r.e1, r.e2, pro, prd, tt) && w < total;
+					const unsigned long long bad = __ballot(hh && !pass);
+					if (bad != 0ull && lane == 0) atomicAdd(&dbg[16], (unsigned long long)__popcll(bad));
+				}
+#endif
+				const unsigned long long pm = __ballot(pass);
+				if (pass) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))) & 127u] = (unsigned long long)own_now | ((unsigned long long)tri << 32);
+				ring_tail += (uint32_t)__popcll(pm);
+				if (count_events && lane == 0) atomicAdd(&dbg[17], (unsigned long long)__popcll(pm));
+				if (ring_tail - ring_head >= 64u) full();
+			};
+#ifndef RMD_SPHERE_AHEAD
+#define RMD_SPHERE_AHEAD 0 // measured (round 6): 38 spilled registers for 7 in the queued mesh kernel (53 for 11 in the lane-per-path one), C3 at 200 spp 130.6 ms against 123.4: not used
+#endif
 			uint32_t own_a = 0, tri_a = 0;
 			search(0u, own_a, tri_a);
 			if constexpr (DEEP && RMD_SPHERE_PREFILTER) {
 				static_assert(sizeof(WalkCarry) >= 128u * sizeof(unsigned long long), "the ring of pairs that passed the pre-test lives in the wave's WalkCarry");
 				uint32_t own_b = 0, tri_b = 0;
 				if (64u < total) search(64u, own_b, tri_b);
-				for (uint32_t base = 0; base < total; base += 128u) {
-					pretest(base, own_a, tri_a);
-					if (base + 64u >= total) break;
-					pretest(base + 64u, own_b, tri_b);
+				if constexpr (RMD_SPHERE_AHEAD && ahead == 2u) {
+					Sph sph_a = load_sph(tri_a), sph_b;
+					RMD_UNDEF(sph_b.c.x) RMD_UNDEF(sph_b.c.y) RMD_UNDEF(sph_b.c.z) RMD_UNDEF(sph_b.r2a)
+					for (uint32_t base = 0; base < total; base += 128u) {
+						pretest_ahead(base, own_a, tri_a, sph_a, tri_b, sph_b, base + 64u < total);
+						if (base + 64u >= total) break;
+						pretest_ahead(base + 64u, own_b, tri_b, sph_b, tri_a, sph_a, base + 128u < total);
+					}
+				} else {
+					for (uint32_t base = 0; base < total; base += 128u) {
+						pretest(base, own_a, tri_a);
+						if (base + 64u >= total) break;
+						pretest(base + 64u, own_b, tri_b);
+					}
 				}
 				if (ring_tail != ring_head) full(); // (fewer than 64 are left: full() is run as soon as 64 wait)
 			} else if constexpr (ahead == 2u) { // two register pairs take turns (no copies: a copy would wait for the load it copies)

@@ -188,7 +188,9 @@ enum { kModeTiles = 0, kModeTilesBuffered = 1, kModeList = 2 };
 #define RMD_SAMPLE_STORE_WT 0
 #endif
 RMD_DEV void store_sample(RMD_GLOBAL double *dst, V3 L) {
-#if RMD_SAMPLE_STORE_WT
+#if RMD_SAMPLE_STORE_WT == 2 // non-temporal stores (what the queued mesh kernel uses: its samples are read by another kernel) — here the samples are read back by a wave of THIS kernel
+	__builtin_nontemporal_store(L.x, dst), __builtin_nontemporal_store(L.y, dst + 1), __builtin_nontemporal_store(L.z, dst + 2);
+#elif RMD_SAMPLE_STORE_WT
 	typedef double d2 __attribute__((ext_vector_type(2)));
 	const d2 xy = {L.x, L.y};
 	asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1" : : "v"(dst), "v"(xy), "v"(L.z) : "memory");
@@ -202,7 +204,7 @@ RMD_DEV void store_sample(RMD_GLOBAL double *dst, V3 L) {
 // agent-scope fence writes this wave's sample stores back before its count; acquire: the last wave invalidates its caches before it reads.
 RMD_DEV void finish_sample_range(const RenderParams &P, const WaveTile &tile, uint32_t wt, uint32_t lane, double *__restrict__ out) {
 	if (P.tile_done == nullptr || wt >= P.n_work) return;
-#if RMD_SAMPLE_STORE_WT
+#if RMD_SAMPLE_STORE_WT == 1
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through sample stores have reached memory before its count is seen
 #else
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's samples leave the XCD's L2 before its count is seen
@@ -1045,6 +1047,18 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 #ifndef RMD_QUEUE_HOLD_HITS
 #define RMD_QUEUE_HOLD_HITS 1
 #endif
+	// Rays held likewise (RMD_QUEUE_HOLD_RAYS): when the rays a GEN / SHADE trip sends to the grids fill a WALK trip together with the stack's, they
+	// do not travel through the stack: each waits in its lane's columns of the wave's LDS — origin, direction, closest plane / sphere hit in the walk
+	// scratch and the carry area (free between walks), the rest where a walking path keeps it anyway (the side area) — and the WALK trip pops only
+	// what fills the other lanes.
+#ifndef RMD_QUEUE_HOLD_RAYS
+#define RMD_QUEUE_HOLD_RAYS 1
+#endif
+	bool rheld = false;
+	double *stash_a = reinterpret_cast<double *>(wave_lds) + lane;                        // [0], [64], [128], [192]: origin, direction.x
+	int32_t *stash_oi = reinterpret_cast<int32_t *>(wave_lds + 256u * sizeof(double)) + lane; // the closest plane / sphere so far
+	double *stash_b = reinterpret_cast<double *>(wave_lds + sizeof(WalkScratch)) + lane;  // [0], [64], [128]: direction.y, .z, the distance of that hit
+	static_assert(sizeof(WalkScratch) >= 256u * sizeof(double) + 64u * sizeof(int32_t) && sizeof(WalkCarry) >= 192u * sizeof(double), "a held ray's columns");
 	bool held = false;
 	V3 h_frag, h_normal, h_T;
 	RMD_UNDEF3(h_frag) RMD_UNDEF3(h_normal) RMD_UNDEF3(h_T)
@@ -1089,7 +1103,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		// did not: the forced-bound test hung)
 		if (RMD_UNLIKELY(trips_left-- == 0ull)) { // (never reached: see below)
 			report_fault(Pt, kFaultQueuedTripLoop, wt);
-			n_hit = 0u, n_ray = 0u, pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu, held = false;
+			n_hit = 0u, n_ray = 0u, pool_items = 0xFFFFFFFFu, next_item = 0xFFFFFFFFu, held = false, rheld = false;
 		}
 		const bool pairs_left = next_item < pool_items; // (false once the launch has no item left: next_item = pool_items = 0xFFFFFFFF)
 		// Which kind of trip.  A FULL trip whenever a stack holds 64 entries — walks first: they are what the other kinds wait for —, else the item's
@@ -1125,7 +1139,9 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		// analysis gives up on them and keeps them — and every address and branch made from them — in vector registers)
 		n_hit = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_hit), n_ray = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_ray);
 		const unsigned long long held_mask = RMD_QUEUE_HOLD_HITS ? __ballot(held) : 0ull;
-		if (held_mask != 0ull) kind = kShade; // (decided when the hits were held: the stack's hits and the held ones fill the trip)
+		const unsigned long long rheld_mask = RMD_QUEUE_HOLD_RAYS ? __ballot(rheld) : 0ull;
+		if (rheld_mask != 0ull) kind = kWalk;      // (decided when the rays were held: the stack's rays and the held ones fill the trip)
+		else if (held_mask != 0ull) kind = kShade; // (likewise the hits)
 		else if (n_ray >= 64u) kind = kWalk;
 		else if (n_hit >= 64u) kind = kShade;
 		else if (pairs_left) kind = kGen;
@@ -1140,24 +1156,37 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		V3 ro, rd, T;
 		RMD_UNDEF(t) RMD_UNDEF3(ro) RMD_UNDEF3(rd) RMD_UNDEF3(T)
 		if (kind == kWalk) {
-			// ---------------- WALK: the top (up to) 64 parked rays, lane i the entry n_ray - n + i; one cooperative walk per grid object
-			const uint32_t n = n_ray < 64u ? n_ray : 64u, base = n_ray - n;
-			active = lane < n;
-			const uint32_t e = active ? base + lane : base; // (a lane beyond n reads the trip's first entry: sane values that nobody uses)
+			// ---------------- WALK: the rays held in their lanes, and in the other lanes the top entries of the ray stack (as many as there are: up to 64 in
+			// all); one cooperative walk per grid object
+			const uint32_t n_rheld = (uint32_t)__popcll(rheld_mask), n_pop = n_ray < 64u - n_rheld ? n_ray : 64u - n_rheld, base = n_ray - n_pop, n = n_rheld + n_pop;
+			const unsigned long long free_mask = ~rheld_mask;
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u)); // free lanes before this one
+			const bool take = !rheld && rank < n_pop;
+			active = rheld || take;
+			const uint32_t e = take ? base + rank : base; // (a lane without a ray reads the trip's first entry: sane values that nobody uses)
 			n_ray = base;
 			constexpr uint32_t cap = kQueuePaths;
-			ro = mk(qld(&q.ray_d[e]), qld(&q.ray_d[cap + e]), qld(&q.ray_d[2u * cap + e]));
-			rd = mk(qld(&q.ray_d[3u * cap + e]), qld(&q.ray_d[4u * cap + e]), qld(&q.ray_d[5u * cap + e]));
-			t = qld(&q.ray_d[9u * cap + e]);
-			const uint32_t st = qld(&q.ray_w[e]), lb = qld(&q.ray_w[cap + e]);
-			oi = (int)(st & 0xFFFFu) - 1;
-			RMD_QSTAMP_FETCH
-			// the rest of the path's state goes from its entry to the lane's column of the side area, and comes back behind the walk
-			side_d[0] = qld(&q.ray_d[6u * cap + e]), side_d[64] = qld(&q.ray_d[7u * cap + e]), side_d[128] = qld(&q.ray_d[8u * cap + e]);
-			side_w[0] = st, side_w[64] = lb;
+			uint32_t lb = 0u;
+			if (!rheld) {
+				ro = mk(qld(&q.ray_d[e]), qld(&q.ray_d[cap + e]), qld(&q.ray_d[2u * cap + e]));
+				rd = mk(qld(&q.ray_d[3u * cap + e]), qld(&q.ray_d[4u * cap + e]), qld(&q.ray_d[5u * cap + e]));
+				t = qld(&q.ray_d[9u * cap + e]);
+				const uint32_t st = qld(&q.ray_w[e]);
+				lb = qld(&q.ray_w[cap + e]);
+				oi = (int)(st & 0xFFFFu) - 1;
+				// the rest of the path's state goes from its entry to the lane's column of the side area, and comes back behind the walk
+				side_d[0] = qld(&q.ray_d[6u * cap + e]), side_d[64] = qld(&q.ray_d[7u * cap + e]), side_d[128] = qld(&q.ray_d[8u * cap + e]);
+				side_w[0] = st, side_w[64] = lb;
 #if RMD_QUEUE_SIDE_ALL
-			side_w[128] = qld(&q.ray_w[2u * cap + e]), side_w[192] = qld(&q.ray_w[3u * cap + e]);
+				side_w[128] = qld(&q.ray_w[2u * cap + e]), side_w[192] = qld(&q.ray_w[3u * cap + e]);
 #endif
+			} else { // a held ray: out of its lane's columns (its side-area column was filled when it was held)
+				ro = mk(stash_a[0], stash_a[64], stash_a[128]);
+				rd = mk(stash_a[192], stash_b[0], stash_b[64]);
+				t = stash_b[128], oi = stash_oi[0];
+			}
+			rheld = false;
+			RMD_QSTAMP_FETCH
 			// Walks put aside (grid_walk.hpp: cut_lanes): a call with many walkers stops stepping under its last K rays and ends under its last 2K
 			// walkers; what is left of such a walk — its DDA state — goes back onto the ray stack with the ray (kRayCarried) and the walk goes on in
 			// the trip that pops it, beside that trip's new rays.  The state travels through the wave's WalkCarry in LDS, lane by lane, the way
@@ -1170,9 +1199,12 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 					carry->rem[0][lane] = qld(&q.ray_w[6u * cap + e]), carry->rem[1][lane] = qld(&q.ray_w[7u * cap + e]), carry->rem[2][lane] = qld(&q.ray_w[8u * cap + e]);
 				}
 			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier(); // (every held ray is out of the walk scratch and the carry area before the walk writes to them)
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			const bool cut = n >= kWalkCutMinWalkers; // (every walker of such a call takes at least one step: walks always finish)
 			const uint32_t cut_lanes = cut ? Pt.walk_cut & 0xffu : 0u, cut_round = cut ? (Pt.walk_cut >> 8) & 0xffu : 0u;
-			intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, active, ro, rd, t, oi, sub, Pt.debug_flags & ~16u /* (this body's own stamps use the counters) */, Pt.debug_counters, cut_lanes, carry, &carried, cut_round);
+			intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, active, ro, rd, t, oi, sub, Pt.debug_flags, (Pt.debug_flags & 16u) && Pt.debug_counters ? Pt.debug_counters + 16 : Pt.debug_counters /* (the walk's own phase clocks land behind this body's: counters 24 .. 31) */, cut_lanes, carry, &carried, cut_round);
 			RMD_QSTAMP(3u)
 			T = mk(side_d[0], side_d[64], side_d[128]);
 			rng_block = side_w[0] >> 16;
@@ -1256,9 +1288,28 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 #endif
 		// ---------------- the rays that have to walk (and the walks that were put aside): pushed onto the ray stack, consecutive entries for the lanes that push
 		// (a WALK trip's lanes have read everything they need of their own entries — by loads that precede these stores in program order)
+		bool rhold = false;
 		{
 			const unsigned long long pm = __ballot(to_ray);
-			if (pm != 0ull) {
+			// held where they are when the next trip walks them anyway: this trip's rays and the stack's fill a WALK trip (a WALK trip's own rays — the
+			// walks it puts aside — go back onto the stack: their DDA state sits in the carry area's columns)
+			rhold = RMD_QUEUE_HOLD_RAYS && kind != kWalk && pm != 0ull && n_ray + (uint32_t)__popcll(pm) >= 64u;
+			if (rhold) {
+				if (to_ray) {
+					stash_a[0] = ro.x, stash_a[64] = ro.y, stash_a[128] = ro.z, stash_a[192] = rd.x, stash_b[0] = rd.y, stash_b[64] = rd.z, stash_b[128] = t;
+					stash_oi[0] = oi;
+					side_d[0] = T.x, side_d[64] = T.y, side_d[128] = T.z;
+					side_w[0] = (uint32_t)(oi + 1) | (rng_block << 16), side_w[64] = lobe_bits | (depth << 24);
+#if RMD_QUEUE_SIDE_ALL
+					side_w[128] = pxw, side_w[192] = sector;
+#endif
+				}
+				rheld = to_ray;
+#if RMD_DIAG
+				if ((Pt.debug_flags & 8u) && Pt.debug_counters && lane == 0) atomicAdd(&Pt.debug_counters[23], (unsigned long long)__popcll(pm));
+#endif
+			}
+			if (pm != 0ull && !rhold) {
 				constexpr uint32_t cap = kQueuePaths;
 				const uint32_t e = n_ray + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
 				if (to_ray) {
@@ -1276,6 +1327,12 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 					}
 				}
 				n_ray += (uint32_t)__popcll(pm);
+#if RMD_DIAG
+				if ((Pt.debug_flags & 8u) && Pt.debug_counters && lane == 0) { // rays pushed; of them walks that were put aside
+					atomicAdd(&Pt.debug_counters[19], (unsigned long long)__popcll(pm));
+					if (kind == kWalk) atomicAdd(&Pt.debug_counters[22], (unsigned long long)__popcll(pm));
+				}
+#endif
 			}
 		}
 		RMD_QSTAMP(4u)
@@ -1323,11 +1380,14 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 		{
 			const unsigned long long pm = __ballot(park);
 			const uint32_t n_park = (uint32_t)__popcll(pm);
-			const bool hold = RMD_QUEUE_HOLD_HITS && n_park != 0u && n_ray < 64u && n_hit + n_park >= 64u; // = the rule above would select a full SHADE trip next
+			const bool hold = RMD_QUEUE_HOLD_HITS && n_park != 0u && !rhold && n_ray < 64u && n_hit + n_park >= 64u; // = the rule above would select a full SHADE trip next (no rays are held: the next trip would be theirs)
 			// (unconditional copies: the held values are made here for every lane, so that nothing of them is live across the trip's other phases)
 			h_frag = frag, h_normal = normal, h_T = T;
 			h_st = (uint32_t)oi | (rng_block << 16), h_lb = lobe_bits | (depth << 24), h_px = pxw, h_sector = sector;
 			held = hold && park;
+#if RMD_DIAG
+			if ((Pt.debug_flags & 8u) && Pt.debug_counters && lane == 0 && n_park != 0u) atomicAdd(&Pt.debug_counters[hold ? 21 : 20], (unsigned long long)n_park);
+#endif
 			if (pm != 0ull && !hold) {
 				constexpr uint32_t cap = kQueuePaths;
 				const uint32_t e = n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));

@@ -35,7 +35,7 @@ def account_for_off_pixels(gpu_ctx, oracle, sc, st, cam, spp, frame, ref, ok, la
           whose vertex sequence DIFFERS (an ulp of libm turned a hit into a miss: a flipped sample), and
       (4) every off pixel holds a flipped sample or a grazing one (same sequence, outside 1e-9 relative, inside 1e-12 absolute).
     The number of off pixels is bounded by `limit` of the frame (the 1,000,000-sample campaign found 0 flipped samples: profiles/r04_parity_campaign.txt)
-    and the counts are recorded (gpurun_out/r05_off_pixels.jsonl on the GPU box -> profiles/)."""
+    and the counts are recorded (gpurun_out/off_pixels.jsonl on the GPU box -> profiles/)."""
     import json
     import os
 
@@ -81,7 +81,7 @@ def account_for_off_pixels(gpu_ctx, oracle, sc, st, cam, spp, frame, ref, ok, la
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         if os.path.isdir(os.path.join(root, "gpurun_out")):
-            with open(os.path.join(root, "gpurun_out", "r05_off_pixels.jsonl"), "a") as f:
+            with open(os.path.join(root, "gpurun_out", "off_pixels.jsonl"), "a") as f:
                 f.write(json.dumps(record) + "\n")
     except OSError:
         pass

@@ -8,9 +8,9 @@ cd $GRAFT_REPO_ROOT
 tag=$1; prof=$2
 out=gpurun_out/${tag}_final
 mkdir -p $out
-rm -f gpurun_out/r05_off_pixels.jsonl
+rm -f gpurun_out/off_pixels.jsonl
 timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $out/pytest_gpu.log
-cp gpurun_out/r05_off_pixels.jsonl $out/off_pixels.jsonl 2>/dev/null || true
+cp gpurun_out/off_pixels.jsonl $out/off_pixels.jsonl 2>/dev/null || true
 timeout -k 10 400 python tools/parity_campaign.py 200000 2>&1 | tee $out/parity_campaign.txt
 timeout -k 10 400 python tools/count_mode_diffs.py $out/black_path_pixel_counts.json 2>&1 | tee $out/black_path_pixel_counts.log
 (timeout -k 10 200 python tools/shard_proxy.py C2 500; timeout -k 10 300 python tools/shard_proxy.py C3 500; timeout -k 10 300 python tools/shard_proxy.py C4 100; timeout -k 10 300 python tools/shard_proxy.py C5 200) 2>&1 | tee $out/shard_proxy.txt
