@@ -162,8 +162,9 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
             let mut fb = ptr::null_mut();
             check(ctx, rmd_framebuffer_alloc(ctx, w as u32, h as u32, &mut fb));
             // The tiles' running sums stay RESIDENT in `fb` (zeroed by rmd_framebuffer_alloc: a fresh tile's sums) between passes; what crosses the bus
-            // is what a message carries.  `resident[i]`: the sums of tile i are in THIS worker's framebuffer (with several GPU workers a tile that
-            // goes back to the shared queue takes its sums along in tile.data, and the worker that pops it next uploads them).
+            // is what a message carries.  With ONE GPU worker every tile's sums are always in this framebuffer; with several, a tile that goes back to
+            // the shared queue takes its sums along in tile.data and the worker that pops it next uploads them: below, every popped tile with
+            // `begin != 0` is uploaded when `gpu_workers > 1` (no per-tile table of who holds what: the worker cannot know who rendered the tile last).
             let mut packed: Vec<f64> = Vec::new();
             // samples per pass: all of them at once, or `samples_per_iteration` when progress messages are wanted (:217)
             let pass = if settings.samples_per_iteration != 0 { settings.samples_per_iteration } else { settings.sample_count };

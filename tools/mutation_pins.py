@@ -116,6 +116,10 @@ def main_expectation(args, L):
         failed = []
         if not ratio <= 1.15:
             failed.append("pooled squared distance / pooled variance = %.3f > 1.15" % ratio)
+        if not ratio >= 0.87:
+            # two-sided: the PNG scatters LESS about this row's expectation than this row's own noise allows — the row's renders are noisier than the
+            # reference's (a sampler with the same expectation and another variance shows here and nowhere else)
+            failed.append("pooled squared distance / pooled variance = %.3f < 0.87: the PNG is less noisy than this restatement's renders" % ratio)
         worst = (None, 0.0)
         for name, m in reg.items():
             mm = m[:, :, None] & live

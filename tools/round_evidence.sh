@@ -15,4 +15,5 @@ timeout -k 10 400 python tools/parity_campaign.py 200000 2>&1 | tee $out/parity_
 timeout -k 10 400 python tools/count_mode_diffs.py $out/black_path_pixel_counts.json 2>&1 | tee $out/black_path_pixel_counts.log
 (timeout -k 10 200 python tools/shard_proxy.py C2 500; timeout -k 10 300 python tools/shard_proxy.py C3 500; timeout -k 10 300 python tools/shard_proxy.py C4 100; timeout -k 10 300 python tools/shard_proxy.py C5 200) 2>&1 | tee $out/shard_proxy.txt
 for a in "spheres 1920 1080 500 5 0" "spheres 1920 1080 500 5 8" "dragon 1920 1080 500 5 0" "dragon 1920 1080 500 5 8" "dragon 1920 1080 500 5 16"; do timeout -k 10 200 raymond_amd/host/raymond_cli hostapi $a; done 2>&1 | tee $out/host_api.jsonl
-timeout -k 10 900 tools/profile_round.sh $prof 2>&1 | tail -1 | cut -c1-200
+# (the profile round is a call of its own — gpurun's limit is 1200 s a call: `tools/profile_round.sh $prof`; pass a third argument to run it here anyway)
+if [ -n "$3" ]; then timeout -k 10 900 tools/profile_round.sh $prof 2>&1 | tail -1 | cut -c1-200; fi
