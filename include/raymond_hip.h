@@ -234,7 +234,7 @@ enum {
 	                              device memory that is free when the buffer is (re)allocated); a launch whose samples do not fit —
 	                              or whose buffer the device cannot provide — runs as several passes                       */
 	RMD_TUNE_WALK_CUT = 5,     /* RMD_WALK_CUT: K + 1, where a grid-walk call of a wave stops stepping under its last K rays and leaves their
-	                              walks to the wave's next call (0 = the library's choice, K = 4; 1 = every call finishes every walk)      */
+	                              walks to the wave's next call (0 = the library's choice, K = 7; 1 = every call finishes every walk)      */
 	RMD_TUNE_SPLIT_MIN_SAMPLES = 6, /* RMD_SPLIT_MIN_SAMPLES: fewest samples per pixel a work item of a split launch may hold (0 = the library's
 	                              choice: 4 in scenes with grids — two items per wave tile from 4 samples per pixel on — 64 without)      */
 	RMD_TUNE_CHAIN_ITEMS = 7,  /* RMD_CHAIN_ITEMS: split launches of scenes with grids whose persistent waves draw their next work item while the last

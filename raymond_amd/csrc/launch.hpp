@@ -62,7 +62,7 @@ constexpr uint32_t kSortedMinSamples = RMD_SORTED_MIN_SAMPLES;
 #endif
 constexpr uint32_t kChainMaxSamples = RMD_CHAIN_MAX_SAMPLES;
 // walks put aside (grid_walk.hpp: cut_lanes): a walk call leaves its last K walkers to the wave's next call
-constexpr uint32_t kWalkCutDefault = 4;
+constexpr uint32_t kWalkCutDefault = 7; // (round 6: 4 -> 7 — the queued form's walks have 60 rays: C3 at 200 spp 120.1 -> 118.9 ms; the lane-per-path form times within 1 % for 2 .. 12)
 // largest |roughness| a material may have: keeps the GGX sampling angle below 2^45 (device_core.hpp, sincos_cw)
 constexpr double kMaxRoughness = 512.0;
 // smallest non-zero |roughness|: the specular weight's denominator holds (roughness^2 / 8)^2 (device_core.hpp: next_ray), which must not underflow
