@@ -202,7 +202,8 @@ typedef struct rmd_tile_rect {
  *                           the depth's own block: same distribution, different samples.  ABI 3 changed no sample, only which
  *                           rmd_settings.flags value ends black paths in scenes with grids; ABI 4 changed no sample either: it added
  *                           RMD_ERR_DEVICE_FAULT, rmd_reduce_framebuffer_async, rmd_launch_info.waves_per_workgroup and the rule for
- *                           non-finite scene parameters below.)
+ *                           non-finite scene parameters below; ABI 5 changed no sample: rmd_launch_info.queued, RMD_TUNE_PATH_QUEUES,
+ *                           and every allocating entry point behind a catch.)
  * (One Philox evaluation per path segment, and no RNG state beyond a block counter and those 22 bits.)
  */
 
