@@ -1175,9 +1175,14 @@ def test_path_queues_do_not_change_the_image(gpu_ctx, small_mesh_scene, oracle):
     tiles = generate_tiles(W, H, (32, 32))
     T = abi
     keys = (T.RMD_TUNE_PATH_QUEUES, T.RMD_TUNE_SAMPLE_SPLIT, T.RMD_TUNE_SCRATCH_CAP_MB, T.RMD_TUNE_LAUNCH_FORM, T.RMD_TUNE_WALK_CUT, T.RMD_TUNE_CHAIN_ITEMS)
-    for sc, spp, dof, bounces, end_black in ((small_mesh_scene, 12, False, 5, False), (small_mesh_scene, 40, True, 8, False), (small_mesh_scene, 24, False, 5, True),
-                                             (small_mesh_scene, 3, False, 2, False), (two, 16, False, 5, False)):
-        ds = render.DeviceScene(gpu_ctx, sc)
+    for sc, spp, dof, bounces, end_black, mask_budget in ((small_mesh_scene, 12, False, 5, False, 0), (small_mesh_scene, 40, True, 8, False, 0), (small_mesh_scene, 24, False, 5, True, 0),
+                                                          (small_mesh_scene, 3, False, 2, False, 0), (small_mesh_scene, 1, False, 5, False, 0), (two, 16, False, 5, False, 0),
+                                                          (small_mesh_scene, 16, False, 5, False, 256)):  # (256 bytes of mask: one bit covers several cells — the walk's general stepping loop)
+        gpu_ctx.set_tunable(T.RMD_TUNE_MASK_BUDGET, mask_budget)
+        try:
+            ds = render.DeviceScene(gpu_ctx, sc)
+        finally:
+            gpu_ctx.set_tunable(T.RMD_TUNE_MASK_BUDGET, 0)
         fb = render.Framebuffer(gpu_ctx, W, H)
         st = Settings(scenes.camera(W, H, aperture_radius=0.4 if dof else 0.0), sample_count=spp, bounce_limit=bounces, seed=77, use_dof=dof, end_black_paths=end_black)
         frames = {}
