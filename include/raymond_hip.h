@@ -212,6 +212,9 @@ typedef struct rmd_scene rmd_scene;
 typedef struct rmd_comm rmd_comm;
 
 /* ---- lifetime ---- */
+/* RMD_ABI_VERSION of the library that was LOADED.  The structs of this header have grown from version to version (rmd_grid_desc::built in 4,
+ * rmd_launch_info::queued in 5): a caller compiled against another version must compare this with its own RMD_ABI_VERSION before its first other
+ * call and refuse to go on when they differ (raymond_amd/lib.py and integration/gpu.rs do). */
 uint32_t rmd_abi_version(void);
 /* One context per GPU (device_ordinal = HIP device index).  Creates its own stream. */
 rmd_status rmd_context_create(int32_t device_ordinal, rmd_context **out);

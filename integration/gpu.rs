@@ -50,7 +50,11 @@ pub enum rmd_context {}
 pub enum rmd_scene {}
 
 #[link(name = "raymond_hip")]
+/// include/raymond_hip.h: RMD_ABI_VERSION this module's struct definitions were written against
+const RMD_ABI_VERSION: u32 = 5;
+
 extern "C" {
+    fn rmd_abi_version() -> u32;
     fn rmd_context_create(device_ordinal: i32, out: *mut *mut rmd_context) -> i32;
     fn rmd_context_destroy(ctx: *mut rmd_context);
     fn rmd_last_error(ctx: *const rmd_context) -> *const c_char;
@@ -150,6 +154,8 @@ pub fn render_tiled_gpu(scene: Scene, settings: Settings, seed: u64) -> TaskHand
         let (queue, sender, thread_count, in_flight) = (queue.clone(), sender.clone(), thread_count.clone(), in_flight.clone());
         let (scene, settings) = (scene.clone(), settings.clone()); // :182-185
         thread::spawn(move || unsafe {
+            // (the structs above have grown from ABI version to version: a library of another version is refused before the first other call)
+            assert_eq!(rmd_abi_version(), RMD_ABI_VERSION, "libraymond_hip.so is of another ABI version than this module");
             let mut ctx = ptr::null_mut();
             check(ptr::null(), rmd_context_create(gpu as i32, &mut ctx));
             let (objects, grids) = flatten(&scene);
