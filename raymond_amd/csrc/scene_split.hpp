@@ -37,7 +37,13 @@ RMD_DEV void axis_pair_test(const DevObject *__restrict__ objs, uint32_t j, bool
 	const bool faces_plus = -rk > 1e-6, faces_minus = rk > 1e-6;
 	const double num = faces_minus ? o_minus - pk : -(o_plus - pk);
 	// (arbitrary_rays: the probes' Scene::intersect on rays given by a test, which may be non-finite in SOME components: always the general test)
-	if (RMD_UNLIKELY(arbitrary_rays || __builtin_amdgcn_ballot_w64(num == 0.0) != 0ull)) { // the sign of a zero numerator is the full dot product's (any lane's: one that carries no ray may send the wave there for nothing)
+	// The numerator's class as ONE unsigned range test of its high word: 2^-700 <= |num| < 2^700 (0x143 .. 0x6BB biased).  Anything else — a ZERO, whose
+	// sign is the full dot product's, a denormal, an infinity, a NaN (a lane that carries no ray may hold anything) — sends the wave down the general
+	// test for this pair; inside the range the quotient below is the IEEE quotient without the division's scaling and special-case instructions
+	// (device_core.hpp: div_lean — the divisor of a lane whose quotient counts is |rd_k| in (1e-6, 1]).
+	const uint32_t num_hi = (uint32_t)(__builtin_bit_cast(unsigned long long, num) >> 32) & 0x7FFFFFFFu;
+	// (only lanes that carry a ray count: the others may hold anything, and two ballots and a scalar AND cost no vector instruction)
+	if (RMD_UNLIKELY(arbitrary_rays || (__builtin_amdgcn_ballot_w64(num_hi - 0x14300000u >= 0x6BB00000u - 0x14300000u) & __builtin_amdgcn_ballot_w64(want)) != 0ull)) {
 		double t;
 		bool first;
 		const bool hit = plane_pair_test_flat(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, t, first);
@@ -46,7 +52,7 @@ RMD_DEV void axis_pair_test(const DevObject *__restrict__ objs, uint32_t j, bool
 		closest = ok ? t : closest, best = ok ? idx : best;
 		return;
 	}
-	const double t = num / __builtin_fabs(rk);
+	const double t = div_lean(num, __builtin_fabs(rk)); // (a lane that faces neither wall divides by whatever its |rd_k| is: nobody reads it)
 	const int idx = faces_plus ? idx_plus : idx_minus;
 	const bool ok = (faces_plus || faces_minus) && t >= 0.0 && want && lex_less(t, idx, closest, best);
 	closest = ok ? t : closest, best = ok ? idx : best;
