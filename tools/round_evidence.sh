@@ -9,7 +9,9 @@ tag=$1; prof=$2
 out=gpurun_out/${tag}_final
 mkdir -p $out
 rm -f gpurun_out/off_pixels.jsonl
-timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $out/pytest_gpu.log
+# (unbuffered and verbose into a file: a quiet call is taken to be hung after seven minutes)
+PYTHONUNBUFFERED=1 timeout -k 10 900 python -u -m pytest tests -x -v -m gpu > $out/pytest_gpu_full.log 2>&1
+tail -3 $out/pytest_gpu_full.log | tee $out/pytest_gpu.log
 cp gpurun_out/off_pixels.jsonl $out/off_pixels.jsonl 2>/dev/null || true
 timeout -k 10 400 python tools/parity_campaign.py 200000 2>&1 | tee $out/parity_campaign.txt
 timeout -k 10 400 python tools/count_mode_diffs.py $out/black_path_pixel_counts.json 2>&1 | tee $out/black_path_pixel_counts.log

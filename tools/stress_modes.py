@@ -1,4 +1,4 @@
-"""The full C3 frame in every launch form (0 = persistent workgroups, 1 = one wave per work item), several splits and several values of the walk cut
+"""The full C3 frame in every launch form (path queues or a lane per path; 0 = persistent workgroups, 1 = one wave per work item), several splits and several values of the walk cut
 (RMD_TUNE_WALK_CUT: 0 = the library's K, 1 = every walk call finishes its walks, 9 = K 8), N frames each: every frame must equal the first one bit
 for bit (work items are drawn in a different order on every run, and with them which walks are put aside when).  python tools/stress_modes.py [frames] [spp]"""
 import sys, os
@@ -16,7 +16,8 @@ with render.Context(0) as ctx:
     ds = render.DeviceScene(ctx, sc)
     fb = render.Framebuffer(ctx, cam.backbuffer_width, cam.backbuffer_height)
     want, bad = None, 0
-    for mode in (0, 1):
+    for queues, mode in ((0, 0), (1, 0), (1, 1)):   # the path queues need the persistent form, so two lane-per-path forms and the queued one
+        ctx.set_tunable(abi.RMD_TUNE_PATH_QUEUES, queues)
         for split in (0, 2, 7):
           for cut in (0, 1, 9):
             ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, mode), ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split), ctx.set_tunable(abi.RMD_TUNE_WALK_CUT, cut)
@@ -29,6 +30,7 @@ with render.Context(0) as ctx:
                 elif got != want:
                     bad += 1
                     print("MISMATCH mode", mode, "split", split, "cut", cut, "frame", i, flush=True)
-            print("mode %d split %d cut %d: %d frames, %d mismatches so far" % (mode, split, cut, frames, bad), flush=True)
+            print("%s mode %d split %d cut %d: %d frames, %d mismatches so far" % (
+                "queued" if ctx.last_launch_info().queued else "lane-per-path", mode, split, cut, frames, bad), flush=True)
     print("stress: %s" % ("FAILED" if bad else "ok"))
     sys.exit(1 if bad else 0)
