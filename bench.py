@@ -266,7 +266,9 @@ def main():
     # is imported and before the first HIP call of the process (the HSA runtime reads its environment once)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("RMD_BENCH_ECHO_ENV"):  # tests/test_distributed_gloo.py: what a rank's environment holds, without touching a GPU
-        print(json.dumps({"rank": os.environ.get("RANK", "0"), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]}), flush=True)
+        # (one write of line + newline: the ranks share the launcher's stdout, and print()'s separate newline can land after the other rank's line)
+        sys.stdout.write(json.dumps({"rank": os.environ.get("RANK", "0"), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]}) + "\n")
+        sys.stdout.flush()
         return
     import torch
 

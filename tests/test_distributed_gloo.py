@@ -145,7 +145,10 @@ def test_bench_starts_its_own_ranks_without_touching_the_gpu_in_the_parent():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]  # both ranks ran bench.py's main()
+    # a rank ran bench.py's main() and refused (the launcher ends the other rank as soon as the first one fails, so
+    # the second refusal is printed or not depending on which came first), and it was the launcher that reported it
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
+    assert "ChildFailedError" in r.stderr or "bench.py FAILED" in r.stderr, r.stderr[-2000:]
     assert "{" not in r.stdout  # no JSON line from a run that measured nothing
 
 
