@@ -230,6 +230,7 @@ RenderParams make_params(const rmd_context *ctx, const rmd_scene *scene, const r
 	P.end_black_paths = (st->flags & RMD_RENDER_TRACE_BLACK_PATHS) ? 0u : ((st->flags & RMD_RENDER_END_BLACK_PATHS) || !scene || (scene->n_grids == 0u && scene->regular)) ? 1u : 0u;
 	P.shade_last_depth = (scene && !scene->regular) ? 1u : 0u;
 	P.axis_pairs = scene ? scene->axis_pairs : 0u;
+	P.visit_mask = scene ? scene->visit_mask : ~0ull, P.grid_mask = scene ? scene->grid_mask : ~0ull;
 	P.fault = ctx ? ctx->d_fault : nullptr;
 	P.walk_batch = rmd::kWalkBatchDefault;
 	if (ctx && ctx->tunable[RMD_TUNE_WALK_BATCH] > 0) P.walk_batch = (uint32_t)ctx->tunable[RMD_TUNE_WALK_BATCH]; // any value gives the same image
@@ -482,6 +483,12 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 	if (!sc) return rmd::fail(ctx, RMD_ERR_OUT_OF_MEMORY, "rmd_scene_create: allocation failed");
 	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids, sc->regular = regular;
 	sc->axis_pairs = axis_pairs;
+	// the object loops' turns (device_types.hpp: RenderParams::visit_mask): a plane tested at its partner's turn or by the axis rule has none
+	sc->visit_mask = 0ull, sc->grid_mask = 0ull;
+	for (uint32_t i = 0; i < n_objects && i < 64u; i++) {
+		if (!(hobj[i].geometry_kind == RMD_GEOM_PLANE && (hobj[i].pair_info & rmd::kPairTestedAtPartner))) sc->visit_mask |= 1ull << i;
+		if (hobj[i].geometry_kind == RMD_GEOM_GRID) sc->grid_mask |= 1ull << i;
+	}
 	for (uint32_t i = 0; i < n_objects; i++) sc->n_grid_objects += objects[i].geometry_kind == RMD_GEOM_GRID ? 1u : 0u;
 	auto upload = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
 		*dst = nullptr;

@@ -131,6 +131,9 @@ struct RenderParams {
 	uint32_t queue_paths;               // paths a wave may have in flight (capacity of each of its queues)
 	uint32_t walk_steps_bound;          // most steps a ray's walk can take in any grid of the scene (res.x + res.y + res.z + 3: grid_walk.hpp) — a walk that is put
 	uint32_t _pad3;                     //   aside takes part in one WALK trip per step at worst: part of render_wave_queued's trip bound
+	unsigned long long visit_mask;      // objects 0 .. 63 whose turn is in the object loops: not the planes tested at their partner's turn or by the axis rule —
+	                                    //   passing one of those by costs a loop a scalar round trip each time (6 of the 8 objects of the reference's scenes).
+	unsigned long long grid_mask;       //   grid_mask: objects 0 .. 63 that are grids (intersect_grids' turns).  Objects from 64 on are visited one by one.
 	unsigned long long sample_magic;    // floor(2^64 / sample_count) + 1, or 0 when sample_count is 1: the multiplier by which a queued path gets its sample's
 	                                    //   number back from its scratch sector (render_kernel.hpp: sample_of_sector)
 };

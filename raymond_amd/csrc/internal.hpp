@@ -73,6 +73,7 @@ struct rmd_scene {
 	uint32_t n_grid_objects = 0; // objects whose geometry is a grid
 	uint32_t mask_words_total = 0; // LDS words of the grids' occupancy masks
 	uint32_t axis_pairs = 0; // RenderParams::axis_pairs
+	unsigned long long visit_mask = ~0ull, grid_mask = ~0ull; // RenderParams::visit_mask / grid_mask
 	uint32_t walk_steps_bound = 0; // RenderParams::walk_steps_bound
 	bool regular = true; // every parameter the kernel reads is finite and inside the class for which ending zero-throughput paths is exact (api.cpp: rmd_scene_create)
 	rmd::DevObject *d_objects = nullptr;

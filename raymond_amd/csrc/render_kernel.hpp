@@ -69,7 +69,8 @@ constexpr uint32_t kStallBound = 1u << 18; // render_wave: trips a wave may take
 template <bool GRID>
 RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids,
                                  const uint32_t *lds_masks, WalkScratch &scr, bool want, V3 ro, V3 rd, double &t_best, uint32_t &sub_best,
-                                 uint32_t axis_pairs, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr, bool arbitrary_rays = false) {
+                                 uint32_t axis_pairs, uint32_t debug_flags = 0, unsigned long long *dbg = nullptr, bool arbitrary_rays = false,
+                                 unsigned long long turns = ~0ull) {
 	double closest = kFMax;
 	int best = -1;
 	uint32_t sub = 0;
@@ -77,7 +78,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 #if RMD_FLAT_OBJECT_TESTS
 	if constexpr (!GRID) {
 		// without grid objects: tests without control flow, the running minimum updated by selects (device_core.hpp: *_test_flat)
-		for (uint32_t i = 0; i < n_objects; i++) {
+		for (uint32_t i = next_turn(~0u, turns); i < n_objects; i = next_turn(i, turns)) {
 			const DevObject &o = objs[i];
 			double t;
 			bool ok;
@@ -102,7 +103,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 		return best;
 	}
 #endif
-	for (uint32_t i = 0; i < n_objects; i++) {
+	for (uint32_t i = next_turn(~0u, turns); i < n_objects; i = next_turn(i, turns)) {
 		const DevObject &o = objs[i];
 		// planes and spheres: the hit is consumed where it is found (device_core.hpp: *_visit)
 		if (o.geometry_kind == 0u) {
@@ -645,7 +646,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 		const bool want = has_ray && !lens_failed;
 		if constexpr (GRID) {
 			if (want && new_ray) {
-				waiting = intersect_simple(objs, Pt.n_objects, grids, true, ro, rd, part_t, part_obj, Pt.axis_pairs);
+				waiting = intersect_simple(objs, Pt.n_objects, grids, true, ro, rd, part_t, part_obj, Pt.axis_pairs, Pt.visit_mask);
 				part_sub = 0u, new_ray = false;
 			}
 			RMD_TSTAMP(tt_simple)
@@ -660,10 +661,11 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 					const bool cut = n_walkers >= kWalkCutMinWalkers && (uint32_t)__popcll(rm) >= kWalkCutMinRunnable;
 					const uint32_t cut_lanes = cut ? Pt.walk_cut & 0xffu : 0u, cut_round = cut ? (Pt.walk_cut >> 8) & 0xffu : 0u;
 					intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters,
-					                      cut_lanes, carry, &carried, cut_round);
+					                      cut_lanes, carry, &carried, cut_round, Pt.grid_mask);
 					waiting = carried;
 				} else { // direct mode (launches of a few samples per pixel): every call finishes its walks — the carry's registers are not worth it there
-					intersect_grids<false>(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters);
+					intersect_grids<false>(objs, Pt.n_objects, grids, lds_masks, scr, want && waiting, ro, rd, part_t, part_obj, part_sub, Pt.debug_flags, Pt.debug_counters, 0u, nullptr, nullptr, 0u,
+					                       Pt.grid_mask);
 					waiting = false;
 				}
 			}
@@ -671,7 +673,7 @@ RMD_DEV void render_wave(const RenderParams &P, KernargWords kernarg_params, con
 			complete = want && !waiting;
 			t = part_t, oi = part_obj, sub = part_sub;
 		} else {
-			oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, Pt.axis_pairs, Pt.debug_flags, Pt.debug_counters);
+			oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, lds_masks, scr, want, ro, rd, t, sub, Pt.axis_pairs, Pt.debug_flags, Pt.debug_counters, false, Pt.visit_mask);
 			complete = want;
 		}
 	}
@@ -860,7 +862,7 @@ RMD_DEV void render_wave_sorted(const RenderParams &P, KernargWords kernarg_para
 		// (the object loop is a chain of scalar loads with a few vector instructions behind each: at a raised priority it is through sooner and the SIMD's
 		// other waves fill what it leaves with their shading — RMD_SORT_OBJ_PRIO, measured −1.7 %)
 		if constexpr (kSortObjPrio != 0) __builtin_amdgcn_s_setprio(kSortObjPrio);
-		const int oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, nullptr, *no_scratch, want, ro, rd, t, sub, Pt.axis_pairs, 0u, nullptr);
+		const int oi = scene_intersect_wave<false>(objs, Pt.n_objects, grids, nullptr, *no_scratch, want, ro, rd, t, sub, Pt.axis_pairs, 0u, nullptr, false, Pt.visit_mask);
 		if constexpr (kSortObjPrio != 0) __builtin_amdgcn_s_setprio(0);
 		// ---------------- classification (the rules of render_wave's phase C)
 		bool terminal = failed, park = false, emitted = false;
@@ -1204,7 +1206,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			const bool cut = n >= kWalkCutMinWalkers; // (every walker of such a call takes at least one step: walks always finish)
 			const uint32_t cut_lanes = cut ? Pt.walk_cut & 0xffu : 0u, cut_round = cut ? (Pt.walk_cut >> 8) & 0xffu : 0u;
-			intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, active, ro, rd, t, oi, sub, Pt.debug_flags, (Pt.debug_flags & 16u) && Pt.debug_counters ? Pt.debug_counters + 16 : Pt.debug_counters /* (the walk's own phase clocks land behind this body's: counters 24 .. 31) */, cut_lanes, carry, &carried, cut_round);
+			intersect_grids<true>(objs, Pt.n_objects, grids, lds_masks, scr, active, ro, rd, t, oi, sub, Pt.debug_flags, (Pt.debug_flags & 16u) && Pt.debug_counters ? Pt.debug_counters + 16 : Pt.debug_counters /* (the walk's own phase clocks land behind this body's: counters 24 .. 31) */, cut_lanes, carry, &carried, cut_round, Pt.grid_mask);
 			RMD_QSTAMP(3u)
 			T = mk(side_d[0], side_d[64], side_d[128]);
 			rng_block = side_w[0] >> 16;
@@ -1275,7 +1277,7 @@ RMD_DEV void render_wave_queued(const RenderParams &P, KernargWords kernarg_para
 			RMD_QSTAMP(1u)
 			// ---------------- src/trace.rs:239, first part — planes, spheres and the grids' boxes (scene_split.hpp)
 			const bool want = active && !failed;
-			const bool enters = intersect_simple(objs, Pt.n_objects, grids, want, ro, rd, t, oi, Pt.axis_pairs);
+			const bool enters = intersect_simple(objs, Pt.n_objects, grids, want, ro, rd, t, oi, Pt.axis_pairs, Pt.visit_mask);
 			to_ray = want && enters;
 			classify = want && !enters;
 			RMD_QSTAMP(2u)

@@ -12,6 +12,24 @@ namespace rmd {
 // walks of the grid objects for the lanes that do, and merges.  Splitting the scan lets a lane WAIT for its walk until
 // enough other lanes of the wave need one too (RenderParams::walk_batch): a walk phase costs about the same for 15 rays as for 45,
 // because the wave steps until its longest walk ends either way.
+// An object loop's next turn: objects 0 .. 63 by the bits of a mask made at scene creation (RenderParams::visit_mask / grid_mask: an object the
+// loop has nothing to do for would cost it a scalar round trip to find that out), objects from 64 on one by one.  Start with i = ~0u.  All-ones =
+// every object (the probes).  The order of the turns is the index order either way.
+#ifndef RMD_VISIT_MASKS
+#define RMD_VISIT_MASKS 1
+#endif
+RMD_DEV uint32_t next_turn(uint32_t i, unsigned long long &m) {
+#if RMD_VISIT_MASKS
+	if (m != 0ull) {
+		i = (uint32_t)__builtin_ctzll(m);
+		m &= m - 1ull;
+		return i;
+	}
+	return i + 1u < 64u ? 64u : i + 1u;
+#else
+	return i + 1u;
+#endif
+}
 RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return (t < t_best) | ((t == t_best) & (obj < obj_best)); } // (no short circuit: three compares and two scalar mask operations, no branch)
 // The walls of an axis-aligned room: up to three pairs of opposite planes with normals exactly +e_k / -e_k (RenderParams::axis_pairs, made by
 // rmd_scene_create in scenes of regular parameters), tested ahead of the object loops — which pass these planes by — with ONE component of the ray
@@ -66,13 +84,13 @@ RMD_DEV void axis_pairs_visit(const DevObject *__restrict__ objs, uint32_t axis_
 #define RMD_FLAT_OBJECT_TESTS 1
 #endif
 RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, bool want, V3 ro, V3 rd,
-                              double &closest, int &best, uint32_t axis_pairs) {
+                              double &closest, int &best, uint32_t axis_pairs, unsigned long long turns = ~0ull) {
 	closest = scalar_const(kFMax), best = -1;
 	bool enters = false;
 	axis_pairs_visit(objs, axis_pairs, want, ro, rd, closest, best);
 #if RMD_FLAT_OBJECT_TESTS
 	// tests without control flow, the running minimum updated by selects (device_core.hpp: *_test_flat)
-	for (uint32_t i = 0; i < n_objects; i++) {
+	for (uint32_t i = next_turn(~0u, turns); i < n_objects; i = next_turn(i, turns)) {
 		const DevObject &o = objs[i];
 		double t;
 		bool ok;
@@ -100,7 +118,7 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 	}
 	return enters;
 #endif
-	for (uint32_t i = 0; i < n_objects; i++) {
+	for (uint32_t i = next_turn(~0u, turns); i < n_objects; i = next_turn(i, turns)) {
 		const DevObject &o = objs[i];
 		if (o.geometry_kind == 0u) {
 			if (o.pair_info != 0u) { // a plane with an exactly opposite partner (device_core.hpp: plane_pair_visit), tested at the later one's turn
@@ -128,8 +146,9 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
 template <bool DEEP = false>
 RMD_DEV void intersect_grids(const DevObject *__restrict__ objs, uint32_t n_objects, const DevGrid *__restrict__ grids, const uint32_t *lds_masks,
                              WalkScratch &scr, bool walkers, V3 ro, V3 rd, double &closest, int &best, uint32_t &sub, uint32_t debug_flags,
-                             unsigned long long *dbg, uint32_t cut_lanes = 0u, WalkCarry *carry = nullptr, bool *carried = nullptr, uint32_t cut_round = 0u) {
-	for (uint32_t i = 0; i < n_objects; i++) {
+                             unsigned long long *dbg, uint32_t cut_lanes = 0u, WalkCarry *carry = nullptr, bool *carried = nullptr, uint32_t cut_round = 0u,
+                             unsigned long long turns = ~0ull) {
+	for (uint32_t i = next_turn(~0u, turns); i < n_objects; i = next_turn(i, turns)) {
 		const DevObject &o = objs[i];
 		if (o.geometry_kind != 2u) continue; // uniform
 		const DevGrid &g = grids[o.grid_index];
