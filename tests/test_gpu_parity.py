@@ -1061,9 +1061,10 @@ def test_role_sorted_trips_equal_the_lane_per_path_kernel(gpu_ctx, oracle, dof, 
     assert ok.mean() >= 0.995, (~ok).sum()
 
 
-@pytest.mark.parametrize("n_spheres", [150, 900])
+@pytest.mark.parametrize("n_spheres", [61, 150, 900])
 def test_role_sorted_trips_with_a_large_object_table(gpu_ctx, oracle, n_spheres):
-    """A scene of many objects leaves the persistent workgroups of the spheres kernel room for fewer LDS pools (150 spheres: 14 waves per
+    """(61 spheres: the room's planes are objects 61 .. 66 — the object loops take the turns of objects 0 .. 63 from a bit mask and visit the rest one
+    by one, RenderParams::visit_mask.)  A scene of many objects leaves the persistent workgroups of the spheres kernel room for fewer LDS pools (150 spheres: 14 waves per
     workgroup; 900: none — the launch falls back to one wave per work item): same frame as the lane-per-path kernel bit for bit in every
     launch form, and the oracle's."""
     from raymond_amd.scene import Material, Object, Scene, Sphere
@@ -1095,6 +1096,46 @@ def test_role_sorted_trips_with_a_large_object_table(gpu_ctx, oracle, n_spheres)
         assert img.tobytes() == frames[(1, 0)].tobytes(), key
     ref = oracle.OracleScene(sc).render_tiles(cam, st, tiles, threads=4)
     assert rel_close(frames[(3, 2)], ref, 1e-9).all(axis=2).mean() >= 0.995
+
+
+def test_object_turns_past_the_masks_reach(gpu_ctx, oracle):
+    """The object loops take the turns of objects 0 .. 63 from bit masks made at scene creation (RenderParams::visit_mask / grid_mask: the planes the
+    axis rule has dealt with are passed by, intersect_grids visits grids only) and visit objects from 64 on one by one.  A mesh scene with 70
+    spheres in FRONT of its room and its mesh (the paired planes and the grid are objects 70 .. 77) and one with 60 (the room straddles 64): the
+    queued and the lane-per-path kernel give the same frame bit for bit, and the oracle's."""
+    from raymond_amd.scene import Material, Object, Sphere
+
+    for n_front in (70, 60):
+        rng = np.random.default_rng(n_front)
+        sc = scenes.mesh_scene(scenes.lumpy_sphere_mesh(11))
+        front = []
+        for i in range(n_front):
+            c = (rng.uniform(-1.8, 1.8), rng.uniform(-0.9, 1.8), rng.uniform(1.5, 4.8))
+            mat = Material.Metal(tuple(rng.uniform(0.2, 1.0, 3)), 0.05) if i % 3 == 0 else Material.Diffuse(tuple(rng.uniform(0.0, 1.0, 3)), 0.3)
+            front.append(Object(Sphere(c, rng.uniform(0.03, 0.1)), mat))
+        sc.objects[:0] = front
+        W, H, spp = 96, 64, 16
+        st = Settings(scenes.camera(W, H), sample_count=spp, bounce_limit=4, seed=9)
+        cam = st.camera_settings
+        tiles = generate_tiles(W, H, (32, 32))
+        ds, fb = render.DeviceScene(gpu_ctx, sc), render.Framebuffer(gpu_ctx, W, H)
+        frames = {}
+        for queues, split in ((0, 4), (1, 4), (1, 1)):
+            gpu_ctx.set_tunable(abi.RMD_TUNE_PATH_QUEUES, queues), gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, split)
+            gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, 2 if split > 1 else 0)  # (2: persistent workgroups although the frame has few work items)
+            try:
+                fb.zero()
+                render.render_tiles(gpu_ctx, ds, cam, st, tiles, fb)
+                frames[(queues, split)] = fb.download()
+                if (queues, split) == (0, 4):
+                    assert gpu_ctx.last_launch_info().queued == 1
+            finally:
+                gpu_ctx.set_tunable(abi.RMD_TUNE_PATH_QUEUES, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_SAMPLE_SPLIT, 0), gpu_ctx.set_tunable(abi.RMD_TUNE_LAUNCH_FORM, 0)
+        fb.close(), ds.close()
+        for key, img in frames.items():
+            assert same_bits(img, frames[(0, 4)]).all(), (n_front, key)
+        ref = oracle.OracleScene(sc).render_tiles(cam, st, tiles, threads=8)
+        assert rel_close(frames[(0, 4)], ref, 1e-9).all(axis=2).mean() >= 0.995, n_front
 
 
 def test_walks_put_aside_do_not_change_the_image(gpu_ctx, small_mesh_scene):
