@@ -484,6 +484,22 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 	sc->ctx = ctx, sc->n_objects = n_objects, sc->n_grids = n_grids, sc->regular = regular;
 	sc->axis_pairs = axis_pairs;
 	// the object loops' turns (device_types.hpp: RenderParams::visit_mask): a plane tested at its partner's turn or by the axis rule has none
+	// the axis pairs as the axis rule reads them, behind the table's last record (device_types.hpp: AxisWalls)
+	rmd::DevObject walls_block;
+	std::memset(&walls_block, 0, sizeof(walls_block));
+	{
+		rmd::AxisWalls walls[3];
+		std::memset(walls, 0, sizeof(walls));
+		for (int k = 0; k < 3; k++) {
+			const uint32_t f = (axis_pairs >> (10 * k)) & 1023u;
+			if (f == 0u) continue;
+			const uint32_t j = f - 1u, i = hobj[j].pair_info & 0x3FFFFFFFu; // the later and the earlier plane of the pair
+			const bool e_plus = (hobj[j].flags & rmd::kObjAxisEarlierIsPlus) != 0u;
+			walls[k].o_plus = e_plus ? hobj[i].origin[k] : hobj[j].origin[k], walls[k].o_minus = e_plus ? hobj[j].origin[k] : hobj[i].origin[k];
+			walls[k].idx_plus = e_plus ? i : j, walls[k].idx_minus = e_plus ? j : i;
+		}
+		std::memcpy(&walls_block, walls, sizeof(walls));
+	}
 	sc->visit_mask = 0ull, sc->grid_mask = 0ull;
 	for (uint32_t i = 0; i < n_objects && i < 64u; i++) {
 		if (!(hobj[i].geometry_kind == RMD_GEOM_PLANE && (hobj[i].pair_info & rmd::kPairTestedAtPartner))) sc->visit_mask |= 1ull << i;
@@ -591,6 +607,7 @@ static rmd_status scene_create_impl(rmd_context *ctx, const rmd_object *objects,
 		d.tri_sph = (const double *)p, d.sph_kb = derived->sphere_kb;
 	}
 	void *p = nullptr;
+	hobj.push_back(walls_block); // (uploaded behind the table; n_objects does not count it)
 	RMD_SCENE_HIP(upload(hobj.data(), hobj.size() * sizeof(rmd::DevObject), &p));
 	sc->d_objects = (rmd::DevObject *)p;
 	RMD_SCENE_HIP(upload(hgrid.data(), hgrid.size() * sizeof(rmd::DevGrid), &p));

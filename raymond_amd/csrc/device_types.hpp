@@ -33,6 +33,16 @@ static_assert(sizeof(DevObject) == 128, "DevObject layout");
 constexpr uint32_t kPairTestedAtPartner = 0x80000000u;
 constexpr uint32_t kPairAxis = 0x40000000u; // with kPairTestedAtPartner, on BOTH planes of an axis pair (kObjAxisPair): pair_info & 0x3FFFFFFF = the partner's index
 
+// The two planes of an axis pair (RenderParams::axis_pairs) as the axis rule uses them (scene_split.hpp: axis_pair_test): the coordinate of the plane
+// with normal +e_k and of the one with normal -e_k, and the two planes' object indices.  Three of them (k = x, y, z) sit behind the object table's last
+// record: scalar loads at ONE address the trip computes, where reading them out of the planes' records is an index computation, a load and six selects
+// per pair and trip.
+struct alignas(32) AxisWalls {
+	double o_plus, o_minus;
+	uint32_t idx_plus, idx_minus, _pad[2];
+};
+static_assert(sizeof(AxisWalls) == 32 && 3 * sizeof(AxisWalls) <= sizeof(DevObject), "the block behind the object table");
+
 // One AccGrid (reference core/src/geometry/acc_grid.rs:27-33), re-laid out at upload for the wave-cooperative walk
 // (grid_walk.hpp).  `cells[c] -> mapping_table[off] = count, idx...` (acc_grid.rs:67-74) becomes
 //   tri_recs[t]                      ONE record per triangle: v0, edge1, edge2 (9 f64; kTriRecStride bytes apart) — 8 MB for the 99k-triangle

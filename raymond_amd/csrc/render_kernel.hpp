@@ -74,7 +74,7 @@ RMD_DEV int scene_intersect_wave(const DevObject *__restrict__ objs, uint32_t n_
 	double closest = kFMax;
 	int best = -1;
 	uint32_t sub = 0;
-	axis_pairs_visit(objs, axis_pairs, want, ro, rd, closest, best, arbitrary_rays); // (the room's walls: scene_split.hpp; `sub` stays 0 for a plane)
+	axis_pairs_visit(objs, n_objects, axis_pairs, want, ro, rd, closest, best, arbitrary_rays); // (the room's walls: scene_split.hpp; `sub` stays 0 for a plane)
 #if RMD_FLAT_OBJECT_TESTS
 	if constexpr (!GRID) {
 		// without grid objects: tests without control flow, the running minimum updated by selects (device_core.hpp: *_test_flat)

@@ -44,16 +44,27 @@ RMD_DEV bool lex_less(double t, int obj, double t_best, int obj_best) { return (
 // Hits are merged with the lexicographic rule (distance, object index), so the order in which the planes are visited does not matter
 // (core/src/scene.rs:54-74 keeps the first object of the closest distance).
 template <int K>
-RMD_DEV void axis_pair_test(const DevObject *__restrict__ objs, uint32_t j, bool want, V3 ro, V3 rd, double &closest, int &best, bool arbitrary_rays) {
+RMD_DEV void axis_pair_test(const DevObject *__restrict__ objs, [[maybe_unused]] const AxisWalls *__restrict__ walls, uint32_t j, bool want, V3 ro, V3 rd, double &closest, int &best, bool arbitrary_rays) {
+#ifndef RMD_AXIS_WALLS_TABLE
+#define RMD_AXIS_WALLS_TABLE 1
+#endif
+#if RMD_AXIS_WALLS_TABLE
+	const AxisWalls &w = walls[K]; // (device_types.hpp: behind the table's last record)
+	const double o_plus = w.o_plus, o_minus = w.o_minus; // the planes with normal +e_k / -e_k (uniform)
+	const int idx_plus = (int)w.idx_plus, idx_minus = (int)w.idx_minus;
+#else
 	const DevObject &o = objs[j];
 	const uint32_t e = o.pair_info & 0x3FFFFFFFu; // the earlier plane of the pair
 	const bool e_plus = (o.flags & kObjAxisEarlierIsPlus) != 0u;
 	const double o_e = o.partner_origin_k, o_j = o.origin[K]; // (the partner's coordinate sits in this object's record: one round of scalar loads, not two)
 	const double o_plus = e_plus ? o_e : o_j, o_minus = e_plus ? o_j : o_e; // the planes with normal +e_k / -e_k (uniform)
 	const int idx_plus = e_plus ? (int)e : (int)j, idx_minus = e_plus ? (int)j : (int)e;
+#endif
 	const double rk = K == 0 ? rd.x : K == 1 ? rd.y : rd.z, pk = K == 0 ? ro.x : K == 1 ? ro.y : ro.z;
 	const bool faces_plus = -rk > 1e-6, faces_minus = rk > 1e-6;
-	const double num = faces_minus ? o_minus - pk : -(o_plus - pk);
+	double num_minus = o_minus - pk, num_plus = -(o_plus - pk);
+	asm volatile("" : "+v"(num_minus), "+v"(num_plus)); // (both computed, one select: with the walls' coordinates loaded the compiler makes two divergent branches of it)
+	const double num = faces_minus ? num_minus : num_plus;
 	// (arbitrary_rays: the probes' Scene::intersect on rays given by a test, which may be non-finite in SOME components: always the general test)
 	// The numerator's class as ONE unsigned range test of its high word: 2^-700 <= |num| < 2^700 (0x143 .. 0x6BB biased).  Anything else — a ZERO, whose
 	// sign is the full dot product's, a denormal, an infinity, a NaN (a lane that carries no ray may hold anything) — sends the wave down the general
@@ -64,6 +75,10 @@ RMD_DEV void axis_pair_test(const DevObject *__restrict__ objs, uint32_t j, bool
 	if (RMD_UNLIKELY(arbitrary_rays || (__builtin_amdgcn_ballot_w64(num_hi - 0x14300000u >= 0x6BB00000u - 0x14300000u) & __builtin_amdgcn_ballot_w64(want)) != 0ull)) {
 		double t;
 		bool first;
+#if RMD_AXIS_WALLS_TABLE
+		const DevObject &o = objs[j];
+		const uint32_t e = o.pair_info & 0x3FFFFFFFu; // the earlier plane of the pair
+#endif
 		const bool hit = plane_pair_test_flat(ld3(objs[e].origin), ld3(objs[e].normal), ld3(o.origin), ld3(o.normal), ro, rd, t, first);
 		const int idx = first ? (int)e : (int)j;
 		const bool ok = hit && want && lex_less(t, idx, closest, best);
@@ -75,10 +90,12 @@ RMD_DEV void axis_pair_test(const DevObject *__restrict__ objs, uint32_t j, bool
 	const bool ok = (faces_plus || faces_minus) && t >= 0.0 && want && lex_less(t, idx, closest, best);
 	closest = ok ? t : closest, best = ok ? idx : best;
 }
-RMD_DEV void axis_pairs_visit(const DevObject *__restrict__ objs, uint32_t axis_pairs, bool want, V3 ro, V3 rd, double &closest, int &best, bool arbitrary_rays = false) {
-	if (axis_pairs & 1023u) axis_pair_test<0>(objs, (axis_pairs & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
-	if ((axis_pairs >> 10) & 1023u) axis_pair_test<1>(objs, ((axis_pairs >> 10) & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
-	if ((axis_pairs >> 20) & 1023u) axis_pair_test<2>(objs, ((axis_pairs >> 20) & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
+RMD_DEV void axis_pairs_visit(const DevObject *__restrict__ objs, uint32_t n_objects, uint32_t axis_pairs, bool want, V3 ro, V3 rd, double &closest, int &best,
+                              bool arbitrary_rays = false) {
+	const AxisWalls *walls = reinterpret_cast<const AxisWalls *>(objs + n_objects); // (one address for the three pairs)
+	if (axis_pairs & 1023u) axis_pair_test<0>(objs, walls, (axis_pairs & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
+	if ((axis_pairs >> 10) & 1023u) axis_pair_test<1>(objs, walls, ((axis_pairs >> 10) & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
+	if ((axis_pairs >> 20) & 1023u) axis_pair_test<2>(objs, walls, ((axis_pairs >> 20) & 1023u) - 1u, want, ro, rd, closest, best, arbitrary_rays);
 }
 #ifndef RMD_FLAT_OBJECT_TESTS
 #define RMD_FLAT_OBJECT_TESTS 1
@@ -87,7 +104,7 @@ RMD_DEV bool intersect_simple(const DevObject *__restrict__ objs, uint32_t n_obj
                               double &closest, int &best, uint32_t axis_pairs, unsigned long long turns = ~0ull) {
 	closest = scalar_const(kFMax), best = -1;
 	bool enters = false;
-	axis_pairs_visit(objs, axis_pairs, want, ro, rd, closest, best);
+	axis_pairs_visit(objs, n_objects, axis_pairs, want, ro, rd, closest, best);
 #if RMD_FLAT_OBJECT_TESTS
 	// tests without control flow, the running minimum updated by selects (device_core.hpp: *_test_flat)
 	for (uint32_t i = next_turn(~0u, turns); i < n_objects; i = next_turn(i, turns)) {
